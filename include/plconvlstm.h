@@ -1,0 +1,146 @@
+/* libplconvlstm -- C ABI of the MI355X (gfx950) ConvLSTM rollout engine.
+ *
+ * The reference (Tomzhuiowewie/Pl-ConvLSTM-GAN) is pure Python/PyTorch and has no FFI; the
+ * entry points below replace, one for one, the PyTorch call sites on its hot path.  Each
+ * declaration names the reference lines whose arithmetic it implements.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative PLC_E* code on failure; the message of
+ *     the last failure on the calling thread is available from plc_last_error();
+ *   - the caller owns every buffer (workspaces included); the library allocates nothing, keeps
+ *     no device state, and is re-entrant;
+ *   - every call is asynchronous on the hipStream_t passed as `stream` (a `void*` here so the
+ *     header needs no HIP include); nothing synchronises;
+ *   - tensors crossing the boundary are fp32, NCHW-contiguous, 16-byte aligned, exactly as the
+ *     reference's modules take and return them.  Internally activations are kept as bf16 in a
+ *     channel-blocked layout ("CB8": [image][C/8][H][W][8]) with fp32 accumulation and an fp32
+ *     cell state.
+ */
+#ifndef PLCONVLSTM_H
+#define PLCONVLSTM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PLC_VERSION 100
+
+enum {
+    PLC_OK = 0,
+    PLC_EINVAL = -1,      /* bad argument (null pointer, non-positive size, misaligned pointer) */
+    PLC_EUNSUPPORTED = -2,/* shape outside the compiled kernel set (see message) */
+    PLC_EWORKSPACE = -3,  /* workspace too small */
+    PLC_EHIP = -4         /* a HIP runtime call failed */
+};
+
+int plc_version(void);
+const char* plc_last_error(void);
+
+/* ---------------------------------------------------------------------------------------
+ * Layout conversion between the boundary layout (NCHW fp32) and the internal CB8 layouts.
+ * `cb8` buffers hold N * ceil(C/8) * H * W * 16 bytes (bf16) or * 32 bytes (fp32 state).
+ * ------------------------------------------------------------------------------------- */
+int plc_nchw_f32_to_cb8_bf16(const float* src, void* dst_cb8, int N, int C, int H, int W, void* stream);
+int plc_cb8_bf16_to_nchw_f32(const void* src_cb8, float* dst, int N, int C, int H, int W, void* stream);
+int plc_nchw_f32_to_cb8_f32(const float* src, float* dst_cb8, int N, int C, int H, int W, void* stream);
+int plc_cb8_f32_to_nchw_f32(const float* src_cb8, float* dst, int N, int C, int H, int W, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Weight packing: PyTorch Conv2d weight [cout][c0+c1][ks][ks] (+ bias [cout] or NULL) ->
+ * MFMA A-fragment order.  c0/c1 are the channel counts of the two concatenated inputs
+ * (c1 = 0 for a plain conv).  mode: 0 plain, 1 ConvLSTM gate conv (rows regrouped so the four
+ * gates of a hidden channel meet in one lane), 2 conv feeding PixelShuffle(2).
+ * Sizes: plc_packed_weight_bytes / plc_packed_bias_bytes.
+ * ------------------------------------------------------------------------------------- */
+enum { PLC_PACK_PLAIN = 0, PLC_PACK_LSTM = 1, PLC_PACK_PIXSHUF = 2 };
+size_t plc_packed_weight_bytes(int cout, int c0, int c1, int ks);
+size_t plc_packed_bias_bytes(int cout);
+int plc_pack_conv_weight(const float* w, const float* bias, void* wpk, float* bpk,
+                         int cout, int c0, int c1, int ks, int mode, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * ConvLSTM cell, forward.  Replaces ConvLSTMCell.forward (src/models/convlstm.py:16-28):
+ *   z = conv3x3(cat[x, h]) + b ; i,f,o = sigmoid(z[0:3Ch]) ; g = tanh(z[3Ch:4Ch]) ;
+ *   c' = f*c + i*g ; h' = o*tanh(c')          (gate order i,f,o,g; input order [x | h])
+ * The gate conv runs as an implicit GEMM on v_mfma_f32_32x32x16_bf16 with the activations and
+ * the state update fused into the epilogue.
+ *
+ * plc_convlstm_cell_fwd_cb8: operands already in the internal layouts (the rollout's primitive).
+ *   x: CB8 bf16 [B][Cin/8][H][W][8], h: CB8 bf16 [B][Ch/8]..., c_in/c_out: CB8 fp32,
+ *   h_out: CB8 bf16, gates: NULL or CB8 bf16 [B][4Ch/8][H][W][8] (i,f,o,g saved for backward),
+ *   wpk/bpk from plc_pack_conv_weight(mode = PLC_PACK_LSTM).
+ * plc_convlstm_cell_fwd: boundary layout (NCHW fp32) in and out; `workspace` must hold
+ *   plc_convlstm_cell_workspace_bytes(...) bytes.
+ * Supported: Cin, Ch multiples of 8 with (Cin, Ch) in {(16,16), (16,32)}.
+ * ------------------------------------------------------------------------------------- */
+int plc_convlstm_cell_fwd_cb8(const void* x, const void* h, const float* c_in,
+                              const void* wpk, const float* bpk,
+                              void* h_out, float* c_out, void* gates,
+                              int B, int Cin, int Ch, int H, int W, void* stream);
+size_t plc_convlstm_cell_workspace_bytes(int B, int Cin, int Ch, int H, int W);
+int plc_convlstm_cell_fwd(const float* x, const float* h, const float* c,
+                          const float* weight, const float* bias,
+                          float* h_next, float* c_next,
+                          void* workspace, size_t workspace_bytes,
+                          int B, int Cin, int Ch, int H, int W, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Generator rollout, forward.  Replaces Generator.forward (src/models/generator.py:94-205):
+ * coord-conv stem (coordconv.py:3-10 + generator.py:166-168), two stacked ConvLSTM cells
+ * unrolled over T (generator.py:170-171), PixelShuffle upsample blocks (generator.py:24-28,
+ * 174-176), residual / target bilinear resize (generator.py:179-195), DEM and land-use gates
+ * (attention.py:12-13, 25-26; evaluated once per call, they do not depend on t) and the two
+ * output convs (generator.py:67-71, 202).
+ * ------------------------------------------------------------------------------------- */
+typedef struct plc_rollout_desc {
+    /* sizes */
+    int B, T, H, W;          /* rain_lr is [B][T][1][H][W] */
+    int C1, C2;              /* hidden_dims */
+    int L;                   /* land-use channels */
+    int dem_H, dem_W;        /* dem is [B][1][dem_H][dem_W] */
+    int lu_H, lu_W;          /* lu  is [B][L][lu_H][lu_W] */
+    int n_blocks;            /* PixelShuffle(2) blocks */
+    int mid_H, mid_W;        /* size after the residual bilinear resize (== H*2^n_blocks if none) */
+    int out_H, out_W;        /* final size (after the optional resize to target_size) */
+    float mid_scale_h, mid_scale_w;   /* source/destination coordinate scales of the residual resize */
+    float out_scale_h, out_scale_w;   /* ... of the resize to target_size */
+    int save_for_backward;   /* keep gate activations in the workspace */
+    /* inputs (fp32, device) */
+    const float* rain;
+    const float* dem;
+    const float* lu;
+    const float* row_tab;    /* linspace(0,1,H)  [H] */
+    const float* col_tab;    /* linspace(0,1,W)  [W] */
+    /* parameters (fp32, device, PyTorch layouts; state_dict names in comments) */
+    const float* init_w; const float* init_b;       /* init_conv.{weight,bias}      [C1][3][3][3]   */
+    const float* cell1_w; const float* cell1_b;     /* cell1.conv.*                 [4C1][2C1][3][3]*/
+    const float* cell2_w; const float* cell2_b;     /* cell2.conv.*                 [4C2][C1+C2][3][3] */
+    const float* dem0_w; const float* dem0_b;       /* dem_attn.conv.0.*            [C2/2][1][3][3] */
+    const float* dem2_w; const float* dem2_b;       /* dem_attn.conv.2.*            [C2][C2/2][1][1]*/
+    const float* lu0_w; const float* lu0_b;         /* lu_attn.conv.0.*             [C2/2][L][3][3] */
+    const float* lu2_w; const float* lu2_b;         /* lu_attn.conv.2.*             [C2][C2/2][1][1]*/
+    const float* up_w[8]; const float* up_b[8];     /* upsample_blocks.k.conv.*     [4C2][C2][3][3] */
+    const float* post0_w; const float* post0_b;     /* post_process.0.*             [32][C2][3][3]  */
+    const float* post2_w; const float* post2_b;     /* post_process.2.*             [1][32][3][3]   */
+    /* output (fp32, device): [B][T][1][out_H][out_W] */
+    float* out;
+    /* caller-owned scratch of plc_generator_workspace_bytes(desc) bytes, 256-byte aligned */
+    void* workspace;
+    size_t workspace_bytes;
+} plc_rollout_desc;
+
+size_t plc_generator_workspace_bytes(const plc_rollout_desc* d);
+int plc_generator_rollout_fwd(const plc_rollout_desc* d, void* stream);
+
+/* Introspection used by tests and the benchmark: byte offset inside the workspace of a named
+ * internal buffer ("h1s", "c1s", "h2s", "c2s", "xs", "gates1", "gates2", "gate", "p0"), or
+ * (size_t)-1 if unknown. */
+size_t plc_generator_workspace_offset(const plc_rollout_desc* d, const char* name);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PLCONVLSTM_H */

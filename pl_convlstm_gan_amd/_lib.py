@@ -1,0 +1,96 @@
+"""ctypes binding of libplconvlstm.so (the C ABI declared in include/plconvlstm.h).
+
+The shared library is built in-tree by ``__graft_entry__.build()`` (hipcc, gfx950).  There is
+no fallback: if it is missing or a call fails, a RuntimeError is raised.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libplconvlstm.so")
+
+EXPORTS = (
+    "plc_version", "plc_last_error",
+    "plc_nchw_f32_to_cb8_bf16", "plc_cb8_bf16_to_nchw_f32", "plc_nchw_f32_to_cb8_f32", "plc_cb8_f32_to_nchw_f32",
+    "plc_packed_weight_bytes", "plc_packed_bias_bytes", "plc_pack_conv_weight",
+    "plc_convlstm_cell_fwd_cb8", "plc_convlstm_cell_workspace_bytes", "plc_convlstm_cell_fwd",
+    "plc_generator_workspace_bytes", "plc_generator_rollout_fwd", "plc_generator_workspace_offset",
+)
+
+_f = C.c_void_p   # device pointers travel as plain addresses
+
+
+class RolloutDesc(C.Structure):
+    """Mirror of ``plc_rollout_desc``."""
+    _fields_ = [
+        ("B", C.c_int), ("T", C.c_int), ("H", C.c_int), ("W", C.c_int),
+        ("C1", C.c_int), ("C2", C.c_int), ("L", C.c_int),
+        ("dem_H", C.c_int), ("dem_W", C.c_int), ("lu_H", C.c_int), ("lu_W", C.c_int),
+        ("n_blocks", C.c_int), ("mid_H", C.c_int), ("mid_W", C.c_int), ("out_H", C.c_int), ("out_W", C.c_int),
+        ("mid_scale_h", C.c_float), ("mid_scale_w", C.c_float),
+        ("out_scale_h", C.c_float), ("out_scale_w", C.c_float),
+        ("save_for_backward", C.c_int),
+        ("rain", _f), ("dem", _f), ("lu", _f), ("row_tab", _f), ("col_tab", _f),
+        ("init_w", _f), ("init_b", _f), ("cell1_w", _f), ("cell1_b", _f), ("cell2_w", _f), ("cell2_b", _f),
+        ("dem0_w", _f), ("dem0_b", _f), ("dem2_w", _f), ("dem2_b", _f),
+        ("lu0_w", _f), ("lu0_b", _f), ("lu2_w", _f), ("lu2_b", _f),
+        ("up_w", _f * 8), ("up_b", _f * 8),
+        ("post0_w", _f), ("post0_b", _f), ("post2_w", _f), ("post2_b", _f),
+        ("out", _f), ("workspace", _f), ("workspace_bytes", C.c_size_t),
+    ]
+
+
+_lib = None
+
+
+def lib():
+    """Load (once) and return the shared library with argument types set."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: the HIP extension has not been built "
+            "(run `python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    i, sz, p = C.c_int, C.c_size_t, C.c_void_p
+    L.plc_version.restype = i
+    L.plc_last_error.restype = C.c_char_p
+    for name in ("plc_nchw_f32_to_cb8_bf16", "plc_cb8_bf16_to_nchw_f32", "plc_nchw_f32_to_cb8_f32",
+                 "plc_cb8_f32_to_nchw_f32"):
+        fn = getattr(L, name)
+        fn.restype = i
+        fn.argtypes = [p, p, i, i, i, i, p]
+    L.plc_packed_weight_bytes.restype = sz
+    L.plc_packed_weight_bytes.argtypes = [i, i, i, i]
+    L.plc_packed_bias_bytes.restype = sz
+    L.plc_packed_bias_bytes.argtypes = [i]
+    L.plc_pack_conv_weight.restype = i
+    L.plc_pack_conv_weight.argtypes = [p, p, p, p, i, i, i, i, i, p]
+    L.plc_convlstm_cell_fwd_cb8.restype = i
+    L.plc_convlstm_cell_fwd_cb8.argtypes = [p, p, p, p, p, p, p, p, i, i, i, i, i, p]
+    L.plc_convlstm_cell_workspace_bytes.restype = sz
+    L.plc_convlstm_cell_workspace_bytes.argtypes = [i, i, i, i, i]
+    L.plc_convlstm_cell_fwd.restype = i
+    L.plc_convlstm_cell_fwd.argtypes = [p, p, p, p, p, p, p, p, sz, i, i, i, i, i, p]
+    L.plc_generator_workspace_bytes.restype = sz
+    L.plc_generator_workspace_bytes.argtypes = [C.POINTER(RolloutDesc)]
+    L.plc_generator_rollout_fwd.restype = i
+    L.plc_generator_rollout_fwd.argtypes = [C.POINTER(RolloutDesc), p]
+    L.plc_generator_workspace_offset.restype = sz
+    L.plc_generator_workspace_offset.argtypes = [C.POINTER(RolloutDesc), C.c_char_p]
+    _lib = L
+    return L
+
+
+def check(rc: int, what: str):
+    """Raise with the library's message if a call returned an error code."""
+    if rc != 0:
+        msg = lib().plc_last_error().decode("utf-8", "replace")
+        if rc == -2:
+            raise NotImplementedError(f"{what}: {msg}")
+        if rc == -1:
+            raise ValueError(f"{what}: {msg}")
+        raise RuntimeError(f"{what} failed (code {rc}): {msg}")

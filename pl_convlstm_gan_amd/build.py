@@ -1,0 +1,33 @@
+"""In-tree build of libplconvlstm.so with hipcc for gfx950 (cross-compiles without a GPU)."""
+from __future__ import annotations
+
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(HERE, "csrc", "plc_api.hip")
+OUT = os.path.join(HERE, "libplconvlstm.so")
+DEPS = [SRC] + [os.path.join(HERE, "csrc", f) for f in ("plc_common.h", "plc_conv_kernel.h", "plc_misc_kernels.h")] + \
+       [os.path.join(os.path.dirname(HERE), "include", "plconvlstm.h")]
+
+
+def is_stale() -> bool:
+    if not os.path.exists(OUT):
+        return True
+    t = os.path.getmtime(OUT)
+    return any(os.path.exists(d) and os.path.getmtime(d) > t for d in DEPS)
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    if not force and not is_stale():
+        return OUT
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC", "-o", OUT, SRC]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+    return OUT
+
+
+if __name__ == "__main__":
+    build(force=True)

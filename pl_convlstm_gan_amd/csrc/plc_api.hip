@@ -1,0 +1,530 @@
+// C ABI of libplconvlstm (see include/plconvlstm.h): argument checking, workspace carving and
+// kernel launches.  No allocation, no synchronisation, no global device state.
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/plconvlstm.h"
+#include "plc_conv_kernel.h"
+#include "plc_misc_kernels.h"
+
+// ---------------------------------------------------------------------------------------------
+// errors
+// ---------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+static int plc_fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define PLC_HIP(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess) return plc_fail(PLC_EHIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+#define PLC_REQUIRE(cond, ...)                              \
+    do {                                                    \
+        if (!(cond)) return plc_fail(PLC_EINVAL, __VA_ARGS__); \
+    } while (0)
+
+static inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+extern "C" int plc_version(void) { return PLC_VERSION; }
+extern "C" const char* plc_last_error(void) { return g_err; }
+
+static inline int ew_grid(long long total) {
+    long long b = (total + 255) / 256;
+    return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
+}
+
+// ---------------------------------------------------------------------------------------------
+// layout conversion
+// ---------------------------------------------------------------------------------------------
+extern "C" int plc_nchw_f32_to_cb8_bf16(const float* src, void* dst, int N, int C, int H, int W, void* stream) {
+    PLC_REQUIRE(src && dst && N > 0 && C > 0 && H > 0 && W > 0, "plc_nchw_f32_to_cb8_bf16: bad argument");
+    PLC_REQUIRE(aligned16(dst), "plc_nchw_f32_to_cb8_bf16: dst must be 16-byte aligned");
+    const long long total = (long long)N * cdiv(C, 8) * H * W;
+    hipLaunchKernelGGL(plc_nchw_to_cb8_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream,
+                       src, (uint4*)dst, N, C, H, W);
+    PLC_HIP(hipGetLastError());
+    return PLC_OK;
+}
+
+extern "C" int plc_cb8_bf16_to_nchw_f32(const void* src, float* dst, int N, int C, int H, int W, void* stream) {
+    PLC_REQUIRE(src && dst && N > 0 && C > 0 && H > 0 && W > 0, "plc_cb8_bf16_to_nchw_f32: bad argument");
+    PLC_REQUIRE(aligned16(src), "plc_cb8_bf16_to_nchw_f32: src must be 16-byte aligned");
+    const long long total = (long long)N * cdiv(C, 8) * H * W;
+    hipLaunchKernelGGL(plc_cb8_to_nchw_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream,
+                       (const uint4*)src, dst, N, C, H, W);
+    PLC_HIP(hipGetLastError());
+    return PLC_OK;
+}
+
+static int state_layout(const float* src, float* dst, int N, int C, int H, int W, int dir, void* stream,
+                        const char* who) {
+    PLC_REQUIRE(src && dst && N > 0 && C > 0 && H > 0 && W > 0, "%s: bad argument", who);
+    PLC_REQUIRE(C % 8 == 0, "%s: channel count %d is not a multiple of 8", who, C);
+    const long long total = (long long)N * C * H * W;
+    hipLaunchKernelGGL(plc_state_layout_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream,
+                       src, dst, N, C, H, W, dir);
+    PLC_HIP(hipGetLastError());
+    return PLC_OK;
+}
+extern "C" int plc_nchw_f32_to_cb8_f32(const float* src, float* dst, int N, int C, int H, int W, void* stream) {
+    return state_layout(src, dst, N, C, H, W, 0, stream, "plc_nchw_f32_to_cb8_f32");
+}
+extern "C" int plc_cb8_f32_to_nchw_f32(const float* src, float* dst, int N, int C, int H, int W, void* stream) {
+    return state_layout(src, dst, N, C, H, W, 1, stream, "plc_cb8_f32_to_nchw_f32");
+}
+
+// ---------------------------------------------------------------------------------------------
+// weight packing
+// ---------------------------------------------------------------------------------------------
+static inline int pack_ncb(int c0, int c1) { return cdiv(c0, 8) + cdiv(c1, 8); }
+static inline int pack_nks(int c0, int c1, int ks) { return (ks * ks * pack_ncb(c0, c1) + 1) / 2; }
+// number of 32-row M tiles; LSTM and PixelShuffle convs regroup rows but keep the count
+static inline int pack_nmt(int cout) { return cdiv(cout, 32); }
+
+extern "C" size_t plc_packed_weight_bytes(int cout, int c0, int c1, int ks) {
+    if (cout <= 0 || c0 <= 0 || c1 < 0 || ks <= 0) return 0;
+    return align256((size_t)pack_nmt(cout) * pack_nks(c0, c1, ks) * 64 * 16);
+}
+extern "C" size_t plc_packed_bias_bytes(int cout) {
+    if (cout <= 0) return 0;
+    return align256((size_t)pack_nmt(cout) * 32 * sizeof(float));
+}
+
+extern "C" int plc_pack_conv_weight(const float* w, const float* bias, void* wpk, float* bpk,
+                                    int cout, int c0, int c1, int ks, int mode, void* stream) {
+    PLC_REQUIRE(w && wpk && bpk, "plc_pack_conv_weight: null pointer");
+    PLC_REQUIRE(cout > 0 && c0 > 0 && c1 >= 0 && (ks == 1 || ks == 3), "plc_pack_conv_weight: bad shape");
+    PLC_REQUIRE(mode >= 0 && mode <= 2, "plc_pack_conv_weight: bad mode %d", mode);
+    if (mode != PLC_PACK_PLAIN) PLC_REQUIRE(cout % 32 == 0, "plc_pack_conv_weight: cout %d must be a multiple of 32 for mode %d", cout, mode);
+    PLC_REQUIRE(aligned16(wpk) && aligned16(bpk), "plc_pack_conv_weight: packed buffers must be 16-byte aligned");
+    const int n_mt = pack_nmt(cout), nks = pack_nks(c0, c1, ks);
+    const long long total = (long long)n_mt * nks * 512;
+    hipLaunchKernelGGL(plc_pack_weight_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream,
+                       w, bias, (unsigned short*)wpk, bpk, cout, c0, c1, ks, mode, n_mt, nks, cout / 4);
+    PLC_HIP(hipGetLastError());
+    return PLC_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// conv launch
+// ---------------------------------------------------------------------------------------------
+static PlcTensor tens(const void* p, long long si, long long so) {
+    PlcTensor t;
+    t.p = (char*)p;
+    t.si = si;
+    t.so = so;
+    return t;
+}
+
+template <int NCB0, int NCB1, int NMT, int KS, int STAGE, int EPI>
+static int launch_conv(ConvArgs a, int n_img, int n_mgroups, hipStream_t st) {
+    const int tx = cdiv(a.W, 32);
+    const long long t16 = (long long)n_img * cdiv(a.H, 16) * tx * n_mgroups;
+    a.tiles_x = tx;
+    if (t16 >= 512) {
+        a.tiles_y = cdiv(a.H, 16);
+        hipLaunchKernelGGL((plc_conv_mfma_kernel<NCB0, NCB1, NMT, KS, STAGE, EPI, 16>),
+                           dim3(n_img * a.tiles_x * a.tiles_y, n_mgroups), dim3(256), 0, st, a);
+    } else {
+        a.tiles_y = cdiv(a.H, 8);
+        hipLaunchKernelGGL((plc_conv_mfma_kernel<NCB0, NCB1, NMT, KS, STAGE, EPI, 8>),
+                           dim3(n_img * a.tiles_x * a.tiles_y, n_mgroups), dim3(256), 0, st, a);
+    }
+    PLC_HIP(hipGetLastError());
+    return PLC_OK;
+}
+
+static ConvArgs conv_args(int H, int W, int n_in) {
+    ConvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.H = H;
+    a.W = W;
+    a.n_in = n_in;
+    return a;
+}
+
+// ---------------------------------------------------------------------------------------------
+// ConvLSTM cell
+// ---------------------------------------------------------------------------------------------
+static int cell_fwd_cb8(const void* x, const void* h, const float* c_in, const void* wpk, const float* bpk,
+                        void* h_out, float* c_out, void* gates, int B, int Cin, int Ch, int H, int W,
+                        hipStream_t st) {
+    const long long hw = (long long)H * W;
+    ConvArgs a = conv_args(H, W, B);
+    a.src0 = tens(x, (Cin / 8) * hw * 16, 0);
+    a.src1 = tens(h, (Ch / 8) * hw * 16, 0);
+    a.c_in = tens(c_in, (Ch / 8) * hw * 32, 0);
+    a.out0 = tens(h_out, (Ch / 8) * hw * 16, 0);
+    a.out1 = tens(c_out, (Ch / 8) * hw * 32, 0);
+    a.out2 = tens(gates, (4 * Ch / 8) * hw * 16, 0);
+    a.save_gates = gates != nullptr;
+    a.wpk = (const uint4*)wpk;
+    a.bpk = bpk;
+    if (Cin == 16 && Ch == 16) return launch_conv<2, 2, 2, 3, STAGE_CB8, EPI_LSTM>(a, B, 1, st);
+    if (Cin == 16 && Ch == 32) return launch_conv<2, 4, 4, 3, STAGE_CB8, EPI_LSTM>(a, B, 1, st);
+    return plc_fail(PLC_EUNSUPPORTED,
+                    "ConvLSTM cell (Cin=%d, Ch=%d) is outside the compiled kernel set {(16,16), (16,32)}", Cin, Ch);
+}
+
+extern "C" int plc_convlstm_cell_fwd_cb8(const void* x, const void* h, const float* c_in, const void* wpk,
+                                         const float* bpk, void* h_out, float* c_out, void* gates, int B, int Cin,
+                                         int Ch, int H, int W, void* stream) {
+    PLC_REQUIRE(x && h && c_in && wpk && bpk && h_out && c_out, "plc_convlstm_cell_fwd_cb8: null pointer");
+    PLC_REQUIRE(B > 0 && H > 0 && W > 0, "plc_convlstm_cell_fwd_cb8: non-positive size");
+    PLC_REQUIRE(aligned16(x) && aligned16(h) && aligned16(c_in) && aligned16(wpk) && aligned16(bpk) &&
+                    aligned16(h_out) && aligned16(c_out) && aligned16(gates),
+                "plc_convlstm_cell_fwd_cb8: pointers must be 16-byte aligned");
+    return cell_fwd_cb8(x, h, c_in, wpk, bpk, h_out, c_out, gates, B, Cin, Ch, H, W, (hipStream_t)stream);
+}
+
+struct CellWs {
+    size_t x, h, c, wpk, bpk, ho, co, total;
+};
+static CellWs cell_ws(int B, int Cin, int Ch, int H, int W) {
+    CellWs s;
+    const size_t hw = (size_t)H * W;
+    size_t o = 0;
+    s.x = o; o += align256((size_t)B * cdiv(Cin, 8) * hw * 16);
+    s.h = o; o += align256((size_t)B * cdiv(Ch, 8) * hw * 16);
+    s.c = o; o += align256((size_t)B * cdiv(Ch, 8) * hw * 32);
+    s.wpk = o; o += plc_packed_weight_bytes(4 * Ch, Cin, Ch, 3);
+    s.bpk = o; o += plc_packed_bias_bytes(4 * Ch);
+    s.ho = o; o += align256((size_t)B * cdiv(Ch, 8) * hw * 16);
+    s.co = o; o += align256((size_t)B * cdiv(Ch, 8) * hw * 32);
+    s.total = o;
+    return s;
+}
+
+extern "C" size_t plc_convlstm_cell_workspace_bytes(int B, int Cin, int Ch, int H, int W) {
+    if (B <= 0 || Cin <= 0 || Ch <= 0 || H <= 0 || W <= 0) return 0;
+    return cell_ws(B, Cin, Ch, H, W).total;
+}
+
+extern "C" int plc_convlstm_cell_fwd(const float* x, const float* h, const float* c, const float* weight,
+                                     const float* bias, float* h_next, float* c_next, void* workspace,
+                                     size_t workspace_bytes, int B, int Cin, int Ch, int H, int W, void* stream) {
+    PLC_REQUIRE(x && h && c && weight && h_next && c_next && workspace, "plc_convlstm_cell_fwd: null pointer");
+    PLC_REQUIRE(B > 0 && Cin > 0 && Ch > 0 && H > 0 && W > 0, "plc_convlstm_cell_fwd: non-positive size");
+    PLC_REQUIRE(((uintptr_t)workspace & 255) == 0, "plc_convlstm_cell_fwd: workspace must be 256-byte aligned");
+    if (!((Cin == 16 && Ch == 16) || (Cin == 16 && Ch == 32)))
+        return plc_fail(PLC_EUNSUPPORTED,
+                        "ConvLSTM cell (Cin=%d, Ch=%d) is outside the compiled kernel set {(16,16), (16,32)}", Cin, Ch);
+    const CellWs s = cell_ws(B, Cin, Ch, H, W);
+    if (workspace_bytes < s.total)
+        return plc_fail(PLC_EWORKSPACE, "plc_convlstm_cell_fwd: workspace %zu < %zu bytes", workspace_bytes, s.total);
+    char* ws = (char*)workspace;
+    int rc;
+    if ((rc = plc_nchw_f32_to_cb8_bf16(x, ws + s.x, B, Cin, H, W, stream))) return rc;
+    if ((rc = plc_nchw_f32_to_cb8_bf16(h, ws + s.h, B, Ch, H, W, stream))) return rc;
+    if ((rc = plc_nchw_f32_to_cb8_f32(c, (float*)(ws + s.c), B, Ch, H, W, stream))) return rc;
+    if ((rc = plc_pack_conv_weight(weight, bias, ws + s.wpk, (float*)(ws + s.bpk), 4 * Ch, Cin, Ch, 3,
+                                   PLC_PACK_LSTM, stream)))
+        return rc;
+    if ((rc = cell_fwd_cb8(ws + s.x, ws + s.h, (float*)(ws + s.c), ws + s.wpk, (float*)(ws + s.bpk), ws + s.ho,
+                           (float*)(ws + s.co), nullptr, B, Cin, Ch, H, W, (hipStream_t)stream)))
+        return rc;
+    if ((rc = plc_cb8_bf16_to_nchw_f32(ws + s.ho, h_next, B, Ch, H, W, stream))) return rc;
+    if ((rc = plc_cb8_f32_to_nchw_f32((float*)(ws + s.co), c_next, B, Ch, H, W, stream))) return rc;
+    return PLC_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Generator rollout
+// ---------------------------------------------------------------------------------------------
+struct Packed {
+    size_t w, b;
+};
+struct RolloutPlan {
+    // packed parameters
+    Packed init, cell1, cell2, dem0, dem2, lu0, lu2, up[8], post0, post2;
+    // activations
+    size_t xs, h1s, c1s, h2s, c2s, gates1, gates2;
+    size_t up_out[8];   // output of upsample block k
+    size_t mid, fin;    // after residual resize / after target resize (== previous stage if unused)
+    size_t dem_hr, lu_hr, dem_mid, lu_mid, gate_dem, gate, p0;
+    size_t total;
+    // derived sizes
+    int up_H, up_W;     // size after the PixelShuffle blocks
+    size_t img1, img2;  // bytes of one CB8 bf16 image of C1 / C2 channels at LR size
+};
+
+static int rollout_plan(const plc_rollout_desc* d, RolloutPlan* p) {
+    PLC_REQUIRE(d, "rollout: null descriptor");
+    PLC_REQUIRE(d->B > 0 && d->T > 0 && d->H > 0 && d->W > 0, "rollout: non-positive B/T/H/W");
+    PLC_REQUIRE(d->L > 0 && d->L <= 16, "rollout: lu_channels=%d unsupported (1..16)", d->L);
+    PLC_REQUIRE(d->n_blocks >= 0 && d->n_blocks <= 8, "rollout: n_blocks=%d out of range", d->n_blocks);
+    if (!(d->C1 == 16 && d->C2 == 32))
+        return plc_fail(PLC_EUNSUPPORTED, "rollout: hidden_dims=[%d,%d] is outside the compiled kernel set {[16,32]}",
+                        d->C1, d->C2);
+    PLC_REQUIRE(d->dem_H > 0 && d->dem_W > 0 && d->lu_H > 0 && d->lu_W > 0, "rollout: bad aux size");
+    const int C1 = d->C1, C2 = d->C2, B = d->B, T = d->T;
+    const size_t hw = (size_t)d->H * d->W;
+    p->up_H = d->H << d->n_blocks;
+    p->up_W = d->W << d->n_blocks;
+    PLC_REQUIRE(d->mid_H > 0 && d->mid_W > 0 && d->out_H > 0 && d->out_W > 0, "rollout: bad mid/out size");
+    const size_t ohw = (size_t)d->out_H * d->out_W;
+    size_t o = 0;
+    auto take = [&](size_t bytes) { size_t at = o; o += align256(bytes); return at; };
+    auto pk = [&](int cout, int c0, int c1, int ks) {
+        Packed q;
+        q.w = take(plc_packed_weight_bytes(cout, c0, c1, ks));
+        q.b = take(plc_packed_bias_bytes(cout));
+        return q;
+    };
+    p->init = pk(C1, 3, 0, 3);
+    p->cell1 = pk(4 * C1, C1, C1, 3);
+    p->cell2 = pk(4 * C2, C1, C2, 3);
+    p->dem0 = pk(C2 / 2, 1, 0, 3);
+    p->dem2 = pk(C2, C2 / 2, 0, 1);
+    p->lu0 = pk(C2 / 2, d->L, 0, 3);
+    p->lu2 = pk(C2, C2 / 2, 0, 1);
+    for (int k = 0; k < d->n_blocks; ++k) p->up[k] = pk(4 * C2, C2, 0, 3);
+    p->post0 = pk(32, C2, 0, 3);
+    p->post2 = pk(1, 32, 0, 3);
+    p->img1 = (size_t)(C1 / 8) * hw * 16;
+    p->img2 = (size_t)(C2 / 8) * hw * 16;
+    p->xs = take((size_t)T * B * p->img1);
+    p->h1s = take((size_t)(T + 1) * B * p->img1);
+    p->c1s = take((size_t)(T + 1) * B * p->img1 * 2);
+    p->h2s = take((size_t)(T + 1) * B * p->img2);
+    p->c2s = take((size_t)(T + 1) * B * p->img2 * 2);
+    if (d->save_for_backward) {
+        p->gates1 = take((size_t)T * B * p->img1 * 4);
+        p->gates2 = take((size_t)T * B * p->img2 * 4);
+    } else {
+        p->gates1 = p->gates2 = (size_t)-1;
+    }
+    size_t cur = p->h2s + (size_t)B * p->img2;  // h2_0 .. h2_{T-1}
+    for (int k = 0; k < d->n_blocks; ++k) {
+        const size_t s = (size_t)(d->H << (k + 1)) * (d->W << (k + 1));
+        p->up_out[k] = take((size_t)T * B * (C2 / 8) * s * 16);
+        cur = p->up_out[k];
+    }
+    if (d->mid_H != p->up_H || d->mid_W != p->up_W) {
+        p->mid = take((size_t)T * B * (C2 / 8) * d->mid_H * d->mid_W * 16);
+        cur = p->mid;
+    } else p->mid = cur;
+    if (d->out_H != d->mid_H || d->out_W != d->mid_W) {
+        p->fin = take((size_t)T * B * (C2 / 8) * ohw * 16);
+        cur = p->fin;
+    } else p->fin = cur;
+    p->dem_hr = take((size_t)B * 1 * ohw * 16);
+    p->lu_hr = take((size_t)B * cdiv(d->L, 8) * ohw * 16);
+    p->dem_mid = take((size_t)B * cdiv(C2 / 2, 8) * ohw * 16);
+    p->lu_mid = take((size_t)B * cdiv(C2 / 2, 8) * ohw * 16);
+    p->gate_dem = take((size_t)B * (C2 / 8) * ohw * 16);
+    p->gate = take((size_t)B * (C2 / 8) * ohw * 16);
+    p->p0 = take((size_t)T * B * 4 * ohw * 16);
+    p->total = o;
+    return PLC_OK;
+}
+
+extern "C" size_t plc_generator_workspace_bytes(const plc_rollout_desc* d) {
+    RolloutPlan p;
+    if (rollout_plan(d, &p) != PLC_OK) return 0;
+    return p.total;
+}
+
+extern "C" size_t plc_generator_workspace_offset(const plc_rollout_desc* d, const char* name) {
+    RolloutPlan p;
+    if (!name || rollout_plan(d, &p) != PLC_OK) return (size_t)-1;
+    if (!strcmp(name, "xs")) return p.xs;
+    if (!strcmp(name, "h1s")) return p.h1s;
+    if (!strcmp(name, "c1s")) return p.c1s;
+    if (!strcmp(name, "h2s")) return p.h2s;
+    if (!strcmp(name, "c2s")) return p.c2s;
+    if (!strcmp(name, "gates1")) return p.gates1;
+    if (!strcmp(name, "gates2")) return p.gates2;
+    if (!strcmp(name, "gate")) return p.gate;
+    if (!strcmp(name, "p0")) return p.p0;
+    if (!strcmp(name, "feat")) return p.fin;
+    return (size_t)-1;
+}
+
+extern "C" int plc_generator_rollout_fwd(const plc_rollout_desc* d, void* stream) {
+    RolloutPlan p;
+    int rc = rollout_plan(d, &p);
+    if (rc) return rc;
+    PLC_REQUIRE(d->rain && d->dem && d->lu && d->row_tab && d->col_tab && d->out && d->workspace,
+                "rollout: null tensor pointer");
+    PLC_REQUIRE(d->init_w && d->init_b && d->cell1_w && d->cell1_b && d->cell2_w && d->cell2_b && d->dem0_w &&
+                    d->dem0_b && d->dem2_w && d->dem2_b && d->lu0_w && d->lu0_b && d->lu2_w && d->lu2_b &&
+                    d->post0_w && d->post0_b && d->post2_w && d->post2_b,
+                "rollout: null parameter pointer");
+    for (int k = 0; k < d->n_blocks; ++k) PLC_REQUIRE(d->up_w[k] && d->up_b[k], "rollout: null upsample parameter %d", k);
+    PLC_REQUIRE(((uintptr_t)d->workspace & 255) == 0, "rollout: workspace must be 256-byte aligned");
+    if (d->workspace_bytes < p.total)
+        return plc_fail(PLC_EWORKSPACE, "rollout: workspace %zu < %zu bytes", d->workspace_bytes, p.total);
+
+    hipStream_t st = (hipStream_t)stream;
+    char* ws = (char*)d->workspace;
+    const int B = d->B, T = d->T, H = d->H, W = d->W, C1 = d->C1, C2 = d->C2, L = d->L;
+    const int oH = d->out_H, oW = d->out_W;
+    const long long hw = (long long)H * W, ohw = (long long)oH * oW;
+
+    // ---- parameters -> MFMA fragment order ----------------------------------------------
+    auto pack = [&](const float* w, const float* b, const Packed& q, int cout, int c0, int c1, int ks, int mode) {
+        return plc_pack_conv_weight(w, b, ws + q.w, (float*)(ws + q.b), cout, c0, c1, ks, mode, stream);
+    };
+    if ((rc = pack(d->init_w, d->init_b, p.init, C1, 3, 0, 3, PLC_PACK_PLAIN))) return rc;
+    if ((rc = pack(d->cell1_w, d->cell1_b, p.cell1, 4 * C1, C1, C1, 3, PLC_PACK_LSTM))) return rc;
+    if ((rc = pack(d->cell2_w, d->cell2_b, p.cell2, 4 * C2, C1, C2, 3, PLC_PACK_LSTM))) return rc;
+    if ((rc = pack(d->dem0_w, d->dem0_b, p.dem0, C2 / 2, 1, 0, 3, PLC_PACK_PLAIN))) return rc;
+    if ((rc = pack(d->dem2_w, d->dem2_b, p.dem2, C2, C2 / 2, 0, 1, PLC_PACK_PLAIN))) return rc;
+    if ((rc = pack(d->lu0_w, d->lu0_b, p.lu0, C2 / 2, L, 0, 3, PLC_PACK_PLAIN))) return rc;
+    if ((rc = pack(d->lu2_w, d->lu2_b, p.lu2, C2, C2 / 2, 0, 1, PLC_PACK_PLAIN))) return rc;
+    for (int k = 0; k < d->n_blocks; ++k)
+        if ((rc = pack(d->up_w[k], d->up_b[k], p.up[k], 4 * C2, C2, 0, 3, PLC_PACK_PIXSHUF))) return rc;
+    if ((rc = pack(d->post0_w, d->post0_b, p.post0, 32, C2, 0, 3, PLC_PACK_PLAIN))) return rc;
+    if ((rc = pack(d->post2_w, d->post2_b, p.post2, 1, 32, 0, 3, PLC_PACK_PLAIN))) return rc;
+
+    // ---- t-invariant gates: sigmoid(conv1x1(relu(conv3x3(aux)))) for DEM and land use, multiplied
+    {
+        const long long tot_d = (long long)B * 1 * ohw, tot_l = (long long)B * cdiv(L, 8) * ohw;
+        hipLaunchKernelGGL(plc_resize_nchw_to_cb8_kernel, dim3(ew_grid(tot_d)), dim3(256), 0, st, d->dem,
+                           (uint4*)(ws + p.dem_hr), B, 1, d->dem_H, d->dem_W, oH, oW, 0,
+                           (float)d->dem_H / (float)oH, (float)d->dem_W / (float)oW);
+        hipLaunchKernelGGL(plc_resize_nchw_to_cb8_kernel, dim3(ew_grid(tot_l)), dim3(256), 0, st, d->lu,
+                           (uint4*)(ws + p.lu_hr), B, L, d->lu_H, d->lu_W, oH, oW, 1,
+                           (float)d->lu_H / (float)oH, (float)d->lu_W / (float)oW);
+        PLC_HIP(hipGetLastError());
+        const int mcb = cdiv(C2 / 2, 8);
+        ConvArgs a = conv_args(oH, oW, B);
+        a.src0 = tens(ws + p.dem_hr, ohw * 16, 0);
+        a.out0 = tens(ws + p.dem_mid, mcb * ohw * 16, 0);
+        a.wpk = (const uint4*)(ws + p.dem0.w);
+        a.bpk = (const float*)(ws + p.dem0.b);
+        a.act = ACT_RELU;
+        a.ncb_out = mcb;
+        if ((rc = launch_conv<1, 0, 1, 3, STAGE_CB8, EPI_ACT_CB8>(a, B, 1, st))) return rc;
+
+        a = conv_args(oH, oW, B);
+        a.src0 = tens(ws + p.dem_mid, mcb * ohw * 16, 0);
+        a.out0 = tens(ws + p.gate_dem, (C2 / 8) * ohw * 16, 0);
+        a.wpk = (const uint4*)(ws + p.dem2.w);
+        a.bpk = (const float*)(ws + p.dem2.b);
+        a.act = ACT_SIGMOID;
+        a.ncb_out = C2 / 8;
+        if ((rc = launch_conv<2, 0, 1, 1, STAGE_CB8, EPI_ACT_CB8>(a, B, 1, st))) return rc;
+
+        a = conv_args(oH, oW, B);
+        a.src0 = tens(ws + p.lu_hr, cdiv(L, 8) * ohw * 16, 0);
+        a.out0 = tens(ws + p.lu_mid, mcb * ohw * 16, 0);
+        a.wpk = (const uint4*)(ws + p.lu0.w);
+        a.bpk = (const float*)(ws + p.lu0.b);
+        a.act = ACT_RELU;
+        a.ncb_out = mcb;
+        if (L <= 8) rc = launch_conv<1, 0, 1, 3, STAGE_CB8, EPI_ACT_CB8>(a, B, 1, st);
+        else rc = launch_conv<2, 0, 1, 3, STAGE_CB8, EPI_ACT_CB8>(a, B, 1, st);
+        if (rc) return rc;
+
+        a = conv_args(oH, oW, B);
+        a.src0 = tens(ws + p.lu_mid, mcb * ohw * 16, 0);
+        a.out0 = tens(ws + p.gate, (C2 / 8) * ohw * 16, 0);
+        a.mul = tens(ws + p.gate_dem, (C2 / 8) * ohw * 16, 0);
+        a.wpk = (const uint4*)(ws + p.lu2.w);
+        a.bpk = (const float*)(ws + p.lu2.b);
+        a.act = ACT_SIGMOID;
+        a.ncb_out = C2 / 8;
+        if ((rc = launch_conv<2, 0, 1, 1, STAGE_CB8, EPI_ACT_CB8>(a, B, 1, st))) return rc;
+    }
+
+    // ---- stem over all T*B frames: x_t = relu(conv3x3([rain, row, col])) ------------------
+    {
+        ConvArgs a = conv_args(H, W, B);
+        a.src0 = tens(d->rain, (long long)T * hw * 4, hw * 4);   // n = t*B + b  ->  rain[b][t]
+        a.row_tab = d->row_tab;
+        a.col_tab = d->col_tab;
+        a.out0 = tens(ws + p.xs, p.img1, (long long)B * p.img1);
+        a.wpk = (const uint4*)(ws + p.init.w);
+        a.bpk = (const float*)(ws + p.init.b);
+        a.act = ACT_RELU;
+        a.ncb_out = C1 / 8;
+        if ((rc = launch_conv<1, 0, 1, 3, STAGE_COORD, EPI_ACT_CB8>(a, T * B, 1, st))) return rc;
+    }
+
+    // ---- recurrence -----------------------------------------------------------------------
+    PLC_HIP(hipMemsetAsync(ws + p.h1s, 0, (size_t)B * p.img1, st));
+    PLC_HIP(hipMemsetAsync(ws + p.c1s, 0, (size_t)B * p.img1 * 2, st));
+    PLC_HIP(hipMemsetAsync(ws + p.h2s, 0, (size_t)B * p.img2, st));
+    PLC_HIP(hipMemsetAsync(ws + p.c2s, 0, (size_t)B * p.img2 * 2, st));
+    for (int t = 0; t < T; ++t) {
+        const size_t s1 = (size_t)B * p.img1, s2 = (size_t)B * p.img2;
+        char* g1 = d->save_for_backward ? ws + p.gates1 + (size_t)t * s1 * 4 : nullptr;
+        char* g2 = d->save_for_backward ? ws + p.gates2 + (size_t)t * s2 * 4 : nullptr;
+        if ((rc = cell_fwd_cb8(ws + p.xs + t * s1, ws + p.h1s + t * s1, (const float*)(ws + p.c1s + t * s1 * 2),
+                               ws + p.cell1.w, (const float*)(ws + p.cell1.b), ws + p.h1s + (t + 1) * s1,
+                               (float*)(ws + p.c1s + (t + 1) * s1 * 2), g1, B, C1, C1, H, W, st)))
+            return rc;
+        if ((rc = cell_fwd_cb8(ws + p.h1s + (t + 1) * s1, ws + p.h2s + t * s2, (const float*)(ws + p.c2s + t * s2 * 2),
+                               ws + p.cell2.w, (const float*)(ws + p.cell2.b), ws + p.h2s + (t + 1) * s2,
+                               (float*)(ws + p.c2s + (t + 1) * s2 * 2), g2, B, C1, C2, H, W, st)))
+            return rc;
+    }
+
+    // ---- everything after the recurrence is batched over the T*B frames ----------------------
+    const int NI = T * B;
+    const char* feat = ws + p.h2s + (size_t)B * p.img2;
+    int fh = H, fw = W;
+    for (int k = 0; k < d->n_blocks; ++k) {
+        ConvArgs a = conv_args(fh, fw, NI);
+        a.src0 = tens(feat, (long long)(C2 / 8) * fh * fw * 16, 0);
+        a.out0 = tens(ws + p.up_out[k], (long long)(C2 / 8) * fh * fw * 4 * 16, 0);
+        a.wpk = (const uint4*)(ws + p.up[k].w);
+        a.bpk = (const float*)(ws + p.up[k].b);
+        if ((rc = launch_conv<4, 0, 4, 3, STAGE_CB8, EPI_PIXSHUF_RELU>(a, NI, 1, st))) return rc;
+        feat = ws + p.up_out[k];
+        fh *= 2;
+        fw *= 2;
+    }
+    if (d->mid_H != fh || d->mid_W != fw) {
+        const long long tot = (long long)NI * (C2 / 8) * d->mid_H * d->mid_W;
+        hipLaunchKernelGGL(plc_resize_cb8_kernel, dim3(ew_grid(tot)), dim3(256), 0, st, (const uint4*)feat,
+                           (uint4*)(ws + p.mid), NI, C2 / 8, fh, fw, d->mid_H, d->mid_W, d->mid_scale_h,
+                           d->mid_scale_w);
+        PLC_HIP(hipGetLastError());
+        feat = ws + p.mid;
+        fh = d->mid_H;
+        fw = d->mid_W;
+    }
+    if (oH != fh || oW != fw) {
+        const long long tot = (long long)NI * (C2 / 8) * ohw;
+        hipLaunchKernelGGL(plc_resize_cb8_kernel, dim3(ew_grid(tot)), dim3(256), 0, st, (const uint4*)feat,
+                           (uint4*)(ws + p.fin), NI, C2 / 8, fh, fw, oH, oW, d->out_scale_h, d->out_scale_w);
+        PLC_HIP(hipGetLastError());
+        feat = ws + p.fin;
+    }
+    {
+        ConvArgs a = conv_args(oH, oW, B);
+        a.src0 = tens(feat, (C2 / 8) * ohw * 16, (long long)B * (C2 / 8) * ohw * 16);
+        a.gate = tens(ws + p.gate, (C2 / 8) * ohw * 16, 0);
+        a.out0 = tens(ws + p.p0, 4 * ohw * 16, (long long)B * 4 * ohw * 16);
+        a.wpk = (const uint4*)(ws + p.post0.w);
+        a.bpk = (const float*)(ws + p.post0.b);
+        a.act = ACT_RELU;
+        a.ncb_out = 4;
+        if ((rc = launch_conv<4, 0, 1, 3, STAGE_CB8_GATED, EPI_ACT_CB8>(a, NI, 1, st))) return rc;
+
+        a = conv_args(oH, oW, B);
+        a.src0 = tens(ws + p.p0, 4 * ohw * 16, (long long)B * 4 * ohw * 16);
+        a.out0 = tens(d->out, (long long)T * ohw * 4, ohw * 4);  // n = t*B + b  ->  out[b][t]
+        a.wpk = (const uint4*)(ws + p.post2.w);
+        a.bpk = (const float*)(ws + p.post2.b);
+        a.act = ACT_NONE;
+        a.cout = 1;
+        if ((rc = launch_conv<4, 0, 1, 3, STAGE_CB8, EPI_F32_NCHW>(a, NI, 1, st))) return rc;
+    }
+    return PLC_OK;
+}

@@ -1,0 +1,263 @@
+// Implicit-GEMM KSxKS convolution (stride 1, "same" zero padding) on gfx950 matrix cores,
+// with the consumer's pointwise work fused into the epilogue.
+//
+// GEMM view (per image):  D[row = output channel][col = pixel] = sum_k Wp[row][k] * In[k][col],
+// k = (tap, channel block, channel-in-block).  v_mfma_f32_32x32x16_bf16, weights as the A
+// operand, pixels as the B operand:
+//   * one workgroup (4 waves) owns a TH x 32 pixel tile of one image; the (TH+2) x 34 input
+//     halo tile of every input channel block is staged once into LDS as 16-byte units
+//     [channel block][row][col] (8 channels of one pixel per unit), so the B fragment of a
+//     32-pixel row at any tap is one conflict-free ds_read_b128 per lane at an immediate offset;
+//   * the weights are stationary in registers: a wave holds the A fragments of ONE 32-row
+//     output tile for the whole K (NKS fragments of 16 bytes per lane), pre-packed by
+//     plc_pack_weight_kernel in exactly the lane order the MFMA wants, and sweeps the tile's
+//     pixel rows NREP at a time (NREP independent accumulators);
+//   * the row order inside a 32-row output tile is chosen per epilogue so that everything the
+//     epilogue combines sits in ONE lane: accumulator register 4g+j of lane (half, x) is row
+//     8g + 4*half + j, pixel x.  For the ConvLSTM cell g is the gate (i,f,o,g) and 4*half+j the
+//     hidden channel inside an 8-channel block, so sigma/tanh/state update need no cross-lane
+//     traffic and h'/c' leave as 8/16-byte stores that are contiguous across the wave.
+#pragma once
+#include "plc_common.h"
+
+enum { STAGE_CB8 = 0, STAGE_CB8_GATED = 1, STAGE_COORD = 2 };
+enum { EPI_LSTM = 0, EPI_ACT_CB8 = 1, EPI_PIXSHUF_RELU = 2, EPI_F32_NCHW = 3 };
+enum { ACT_NONE = 0, ACT_RELU = 1, ACT_SIGMOID = 2 };
+
+struct ConvArgs {
+    int H, W;            // input == output spatial size (PixelShuffle epilogue writes 2H x 2W)
+    int tiles_x, tiles_y;
+    int n_in;            // inner image count for PlcTensor addressing
+    int ncb_out;         // EPI_ACT_CB8: number of 8-channel blocks actually stored
+    int cout;            // EPI_F32_NCHW: number of fp32 channels stored
+    int act;             // EPI_ACT_CB8 / EPI_F32_NCHW activation
+    int save_gates;      // EPI_LSTM: also store i,f,o,g (bf16) for the backward pass
+    PlcTensor src0;      // CB8 bf16, first NCB0 channel blocks   (STAGE_COORD: fp32 plane)
+    PlcTensor src1;      // CB8 bf16, next NCB1 channel blocks
+    PlcTensor gate;      // STAGE_CB8_GATED: CB8 bf16 multiplier of src0
+    const float* row_tab;  // STAGE_COORD: linspace(0,1,H)
+    const float* col_tab;  // STAGE_COORD: linspace(0,1,W)
+    const uint4* wpk;    // packed A fragments [M tile][k step][lane] x 16 B
+    const float* bpk;    // packed bias [M tile][32 rows]
+    PlcTensor c_in;      // EPI_LSTM: previous cell state, CB8 fp32
+    PlcTensor out0;      // EPI_LSTM: h' (CB8 bf16); EPI_ACT_CB8/PIXSHUF: out (CB8 bf16); EPI_F32_NCHW: fp32
+    PlcTensor out1;      // EPI_LSTM: c' (CB8 fp32)
+    PlcTensor out2;      // EPI_LSTM: gates i,f,o,g (CB8 bf16, 4*Ch channels) when save_gates
+    PlcTensor mul;       // EPI_ACT_CB8: optional CB8 bf16 tensor multiplied into the output (p may be null)
+};
+
+template <int NCB0, int NCB1, int NMT, int KS, int STAGE, int EPI, int TH>
+__global__ __launch_bounds__(256, 2) void plc_conv_mfma_kernel(const ConvArgs a) {
+    constexpr int NCB = NCB0 + NCB1;
+    constexpr int TAPS = KS * KS;
+    constexpr int UNITS = TAPS * NCB;
+    constexpr int NKS = (UNITS + 1) / 2;
+    constexpr int PAD = KS / 2;
+    constexpr int LH = TH + 2 * PAD;
+    constexpr int LW = 32 + 2 * PAD;
+    constexpr int PLANE = LH * LW;           // units per channel block
+    constexpr int RG = 4 / NMT;              // row groups (waves sharing one M tile)
+    constexpr int RPW = TH / RG;             // rows per wave
+    // rows (N tiles) per pass: 4 accumulators, or 2 when the stationary weights already take
+    // more than ~100 VGPRs (a single 32x32x16 accumulation chain issues back to back anyway)
+    constexpr int NREP_MAX = (NKS * 4 > 100) ? 2 : 4;
+    constexpr int NREP = RPW < NREP_MAX ? RPW : NREP_MAX;
+    constexpr int PASSES = RPW / NREP;
+    static_assert(NMT == 1 || NMT == 2 || NMT == 4, "NMT must be 1, 2 or 4");
+    static_assert(RPW >= 1 && RPW % NREP == 0, "tile rows must split evenly over waves");
+    static_assert(NCB * PLANE * 16 <= 65536, "LDS tile too large");
+
+    __shared__ __attribute__((aligned(16))) uint4 tile[NCB * PLANE];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int half = lane >> 5;
+    const int px = lane & 31;
+    const int m = wave % NMT;
+    const int rg = wave / NMT;
+    const int mt = blockIdx.y * NMT + m;     // global M tile index
+
+    int bid = blockIdx.x;
+    const int tx = bid % a.tiles_x;
+    bid /= a.tiles_x;
+    const int ty = bid % a.tiles_y;
+    const int n = bid / a.tiles_y;
+    const int x0 = tx * 32, y0 = ty * TH;
+    const int H = a.H, W = a.W;
+    const long long plane_b = (long long)H * W * 16;  // bytes per bf16 channel block plane
+
+    // ---- weights: stationary A fragments -------------------------------------------------
+    bf16x8_t wf[NKS];
+    {
+        const uint4* wp = a.wpk + ((long long)mt * NKS) * 64 + lane;
+#pragma unroll
+        for (int s = 0; s < NKS; ++s) wf[s] = __builtin_bit_cast(bf16x8_t, wp[s * 64]);
+    }
+
+    // ---- stage the input halo tile into LDS ----------------------------------------------
+    {
+        const char* s0 = plc_img(a.src0, n, a.n_in);
+        const char* s1 = NCB1 > 0 ? plc_img(a.src1, n, a.n_in) : nullptr;
+        const char* gt = STAGE == STAGE_CB8_GATED ? plc_img(a.gate, n, a.n_in) : nullptr;
+        for (int u = tid; u < NCB * PLANE; u += 256) {
+            const int cb = u / PLANE;
+            const int r = u - cb * PLANE;
+            const int ly = r / LW;
+            const int lx = r - ly * LW;
+            const int gy = y0 - PAD + ly, gx = x0 - PAD + lx;
+            const bool ok = (gy >= 0) & (gy < H) & (gx >= 0) & (gx < W);
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (ok) {
+                const long long pix = ((long long)gy * W + gx) * 16;
+                if (STAGE == STAGE_COORD) {
+                    const float rv = ((const float*)s0)[(long long)gy * W + gx];
+                    v.x = pack_bf2(rv, a.row_tab[gy]);
+                    v.y = pack_bf2(a.col_tab[gx], 0.0f);
+                } else if (STAGE == STAGE_CB8_GATED) {
+                    const uint4 f = *(const uint4*)(s0 + cb * plane_b + pix);
+                    const uint4 g = *(const uint4*)(gt + cb * plane_b + pix);
+                    const float4 f0 = unpack_bf4(make_uint2(f.x, f.y)), f1 = unpack_bf4(make_uint2(f.z, f.w));
+                    const float4 g0 = unpack_bf4(make_uint2(g.x, g.y)), g1 = unpack_bf4(make_uint2(g.z, g.w));
+                    const uint2 lo = pack_bf4(f0.x * g0.x, f0.y * g0.y, f0.z * g0.z, f0.w * g0.w);
+                    const uint2 hi = pack_bf4(f1.x * g1.x, f1.y * g1.y, f1.z * g1.z, f1.w * g1.w);
+                    v = make_uint4(lo.x, lo.y, hi.x, hi.y);
+                } else {
+                    const char* base = (cb < NCB0) ? (s0 + cb * plane_b) : (s1 + (cb - NCB0) * plane_b);
+                    v = *(const uint4*)(base + pix);
+                }
+            }
+            tile[u] = v;
+        }
+    }
+    __syncthreads();
+
+    const char* lds = (const char*)tile;
+    const float4* bias4 = (const float4*)a.bpk + mt * 8;
+
+#pragma unroll 1
+    for (int pass = 0; pass < PASSES; ++pass) {
+        const int row0 = rg * RPW + pass * NREP;
+        f32x16_t acc[NREP];
+        {
+            float4 bv[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) bv[g] = bias4[2 * g + half];
+#pragma unroll
+            for (int r = 0; r < NREP; ++r)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    acc[r][4 * g + 0] = bv[g].x;
+                    acc[r][4 * g + 1] = bv[g].y;
+                    acc[r][4 * g + 2] = bv[g].z;
+                    acc[r][4 * g + 3] = bv[g].w;
+                }
+        }
+        // per-lane LDS byte address of this pass's first row at tap (0,0), channel block 0
+        int abase[NREP];
+#pragma unroll
+        for (int r = 0; r < NREP; ++r) {
+            abase[r] = ((row0 + r) * LW + px) * 16;
+            if (NCB % 2 == 0) abase[r] += half * PLANE * 16;
+        }
+#pragma unroll
+        for (int s = 0; s < NKS; ++s) {
+            // unit u = tap * NCB + cb; lanes 0-31 take unit 2s, lanes 32-63 unit 2s+1
+            const int u0 = 2 * s, u1 = 2 * s + 1;
+            const int t0 = u0 / NCB, c0 = u0 % NCB;
+            const int t1 = (u1 < UNITS) ? u1 / NCB : 0, c1 = (u1 < UNITS) ? u1 % NCB : 0;
+            const int off0 = (c0 * PLANE + (t0 / KS) * LW + (t0 % KS)) * 16;
+            const int off1 = (c1 * PLANE + (t1 / KS) * LW + (t1 % KS)) * 16;
+#pragma unroll
+            for (int r = 0; r < NREP; ++r) {
+                int addr;
+                if (NCB % 2 == 0) addr = abase[r] + off0;          // off1 == off0 + PLANE*16 folded in abase
+                else addr = abase[r] + (half ? off1 : off0);
+                const bf16x8_t bfrag = *(const bf16x8_t*)(lds + addr);
+                acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s], bfrag, acc[r], 0, 0, 0);
+            }
+        }
+
+        // ---- epilogue ----------------------------------------------------------------------
+#pragma unroll
+        for (int r = 0; r < NREP; ++r) {
+            const int gy = y0 + row0 + r, gx = x0 + px;
+            if (gy >= H || gx >= W) continue;
+            const long long pix = (long long)gy * W + gx;
+            if (EPI == EPI_LSTM) {
+                const long long coff = ((long long)mt * H * W + pix) * 32 + half * 16;
+                const long long hoff = ((long long)mt * H * W + pix) * 16 + half * 8;
+                const float4 cp = *(const float4*)(plc_img(a.c_in, n, a.n_in) + coff);
+                float ig[4], fg[4], og[4], gg[4], cn[4], hn[4];
+                const float cpv[4] = {cp.x, cp.y, cp.z, cp.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    ig[j] = fast_sigmoid(acc[r][j]);
+                    fg[j] = fast_sigmoid(acc[r][4 + j]);
+                    og[j] = fast_sigmoid(acc[r][8 + j]);
+                    gg[j] = fast_tanh(acc[r][12 + j]);
+                    cn[j] = fg[j] * cpv[j] + ig[j] * gg[j];
+                    hn[j] = og[j] * fast_tanh(cn[j]);
+                }
+                *(float4*)(plc_img(a.out1, n, a.n_in) + coff) = make_float4(cn[0], cn[1], cn[2], cn[3]);
+                *(uint2*)(plc_img(a.out0, n, a.n_in) + hoff) = pack_bf4(hn[0], hn[1], hn[2], hn[3]);
+                if (a.save_gates) {
+                    // gates tensor: CB8 bf16 with 4*Ch channels in conv-output order (gate-major)
+                    const int cbs = gridDim.y * NMT;  // channel blocks per gate = Ch / 8
+                    char* gp = plc_img(a.out2, n, a.n_in) + pix * 16 + half * 8;
+                    *(uint2*)(gp + (long long)(0 * cbs + mt) * plane_b) = pack_bf4(ig[0], ig[1], ig[2], ig[3]);
+                    *(uint2*)(gp + (long long)(1 * cbs + mt) * plane_b) = pack_bf4(fg[0], fg[1], fg[2], fg[3]);
+                    *(uint2*)(gp + (long long)(2 * cbs + mt) * plane_b) = pack_bf4(og[0], og[1], og[2], og[3]);
+                    *(uint2*)(gp + (long long)(3 * cbs + mt) * plane_b) = pack_bf4(gg[0], gg[1], gg[2], gg[3]);
+                }
+            } else if (EPI == EPI_ACT_CB8) {
+                char* op = plc_img(a.out0, n, a.n_in);
+                const char* mp = a.mul.p ? plc_img(a.mul, n, a.n_in) : nullptr;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int cb = 4 * mt + g;
+                    if (cb >= a.ncb_out) continue;
+                    float v[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float t = acc[r][4 * g + j];
+                        if (a.act == ACT_RELU) t = fmaxf(t, 0.0f);
+                        else if (a.act == ACT_SIGMOID) t = fast_sigmoid(t);
+                        v[j] = t;
+                    }
+                    const long long off = ((long long)cb * H * W + pix) * 16 + half * 8;
+                    if (mp) {
+                        const float4 mv = unpack_bf4(*(const uint2*)(mp + off));
+                        v[0] *= mv.x; v[1] *= mv.y; v[2] *= mv.z; v[3] *= mv.w;
+                    }
+                    *(uint2*)(op + off) = pack_bf4(v[0], v[1], v[2], v[3]);
+                }
+            } else if (EPI == EPI_PIXSHUF_RELU) {
+                // row 8g + 4*half + j  <->  conv channel 4*(8*mt + 4*half + j) + g ; g = 2*i + jj
+                char* op = plc_img(a.out0, n, a.n_in);
+                const int H2 = 2 * H, W2 = 2 * W;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int oy = 2 * gy + (g >> 1), ox = 2 * gx + (g & 1);
+                    const long long off = (((long long)mt * H2 + oy) * W2 + ox) * 16 + half * 8;
+                    *(uint2*)(op + off) = pack_bf4(fmaxf(acc[r][4 * g + 0], 0.0f), fmaxf(acc[r][4 * g + 1], 0.0f),
+                                                   fmaxf(acc[r][4 * g + 2], 0.0f), fmaxf(acc[r][4 * g + 3], 0.0f));
+                }
+            } else {  // EPI_F32_NCHW: channel = 32*mt + 8g + 4*half + j
+                float* op = (float*)plc_img(a.out0, n, a.n_in);
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int ch = 32 * mt + 8 * g + 4 * half + j;
+                        if (ch >= a.cout) continue;
+                        float t = acc[r][4 * g + j];
+                        if (a.act == ACT_RELU) t = fmaxf(t, 0.0f);
+                        else if (a.act == ACT_SIGMOID) t = fast_sigmoid(t);
+                        op[(long long)ch * H * W + pix] = t;
+                    }
+            }
+            __builtin_amdgcn_sched_barrier(0);  // keep the NREP epilogues from interleaving (register pressure)
+        }
+    }
+}

@@ -1,0 +1,206 @@
+// Weight packing, layout conversion and resampling kernels (all HBM-bound, one pass each).
+#pragma once
+#include "plc_common.h"
+
+enum { PACK_PLAIN = 0, PACK_LSTM = 1, PACK_PIXSHUF = 2 };
+
+// Output-channel index of row r (0..31) of M tile mt.  Row r = 8g + j8 (see plc_conv_kernel.h).
+__device__ __forceinline__ int plc_row_to_cout(int mode, int mt, int r, int ch_per_gate) {
+    const int g = r >> 3, j8 = r & 7;
+    if (mode == PACK_LSTM) return g * ch_per_gate + 8 * mt + j8;        // gate-major conv channels
+    if (mode == PACK_PIXSHUF) return 4 * (8 * mt + j8) + g;             // PixelShuffle(2): 4c + 2i + j
+    return 32 * mt + r;
+}
+
+// w: fp32 [cout][c0 + c1][ks][ks] (cross-correlation weights, PyTorch layout)
+// wpk: bf16 [n_mt][nks][64 lanes][8], lane l = (half, row): k index 16 s + 8 half + j is
+//      unit u = 2s + half = tap * ncb + cb, channel 8 cb + j of the block-padded concat [src0 | src1].
+// transposed != 0 packs the data-gradient weights instead: W'[ci][co][ks-1-dy][ks-1-dx] viewed
+//      as a conv from cout (w's dim 0, in blocks of c0=cout) to cin channels.
+__global__ void plc_pack_weight_kernel(const float* __restrict__ w, const float* __restrict__ bias,
+                                       unsigned short* __restrict__ wpk, float* __restrict__ bpk,
+                                       int cout, int c0, int c1, int ks, int mode, int n_mt, int nks,
+                                       int ch_per_gate) {
+    const int ncb0 = (c0 + 7) / 8, ncb1 = (c1 + 7) / 8, ncb = ncb0 + ncb1;
+    const int taps = ks * ks;
+    const long long total = (long long)n_mt * nks * 64 * 8;
+    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const int j = idx & 7;
+        const int lane = (idx >> 3) & 63;
+        const int s = (idx >> 9) % nks;
+        const int mt = (idx >> 9) / nks;
+        const int r = lane & 31, half = lane >> 5;
+        const int u = 2 * s + half;
+        const int tap = u / ncb, cb = u % ncb;
+        float v = 0.0f;
+        const int o = plc_row_to_cout(mode, mt, r, ch_per_gate);
+        if (tap < taps && o < cout) {
+            int ci = -1;
+            if (cb < ncb0) {
+                if (8 * cb + j < c0) ci = 8 * cb + j;
+            } else {
+                if (8 * (cb - ncb0) + j < c1) ci = c0 + 8 * (cb - ncb0) + j;
+            }
+            if (ci >= 0) v = w[(((long long)o * (c0 + c1) + ci) * ks + tap / ks) * ks + tap % ks];
+        }
+        wpk[idx] = f2bf(v);
+    }
+    if (bpk) {
+        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_mt * 32; i += gridDim.x * blockDim.x) {
+            const int o = plc_row_to_cout(mode, i >> 5, i & 31, ch_per_gate);
+            bpk[i] = (bias && o < cout) ? bias[o] : 0.0f;
+        }
+    }
+}
+
+// NCHW fp32 -> CB8 bf16 (channels padded with zeros to a multiple of 8).
+__global__ void plc_nchw_to_cb8_kernel(const float* __restrict__ src, uint4* __restrict__ dst,
+                                       int N, int C, int H, int W) {
+    const int ncb = (C + 7) / 8;
+    const long long hw = (long long)H * W;
+    const long long total = (long long)N * ncb * hw;
+    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const long long pix = idx % hw;
+        const int cb = (idx / hw) % ncb;
+        const long long n = idx / (hw * ncb);
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int c = 8 * cb + j;
+            v[j] = c < C ? src[(n * C + c) * hw + pix] : 0.0f;
+        }
+        dst[idx] = make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7]));
+    }
+}
+
+// CB8 bf16 -> NCHW fp32
+__global__ void plc_cb8_to_nchw_kernel(const uint4* __restrict__ src, float* __restrict__ dst,
+                                       int N, int C, int H, int W) {
+    const int ncb = (C + 7) / 8;
+    const long long hw = (long long)H * W;
+    const long long total = (long long)N * ncb * hw;
+    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const long long pix = idx % hw;
+        const int cb = (idx / hw) % ncb;
+        const long long n = idx / (hw * ncb);
+        const uint4 u = src[idx];
+        const float4 a = unpack_bf4(make_uint2(u.x, u.y)), b = unpack_bf4(make_uint2(u.z, u.w));
+        const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int c = 8 * cb + j;
+            if (c < C) dst[(n * C + c) * hw + pix] = v[j];
+        }
+    }
+}
+
+// NCHW fp32 <-> CB8 fp32 (cell state); dir 0: NCHW -> CB8, dir 1: CB8 -> NCHW.  C % 8 == 0.
+__global__ void plc_state_layout_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                        int N, int C, int H, int W, int dir) {
+    const long long hw = (long long)H * W;
+    const long long total = (long long)N * C * hw;
+    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        // idx enumerates the CB8 side: [n][cb][pix][j]
+        const int j = idx & 7;
+        const long long pix = (idx >> 3) % hw;
+        const int cb = ((idx >> 3) / hw) % (C / 8);
+        const long long n = (idx >> 3) / (hw * (C / 8));
+        const long long nchw = (n * C + 8 * cb + j) * hw + pix;
+        if (dir == 0) dst[idx] = src[nchw];
+        else dst[nchw] = src[idx];
+    }
+}
+
+// PyTorch 'bilinear', align_corners=False source coordinate for destination index d.
+__device__ __forceinline__ void plc_bilinear_coord(int d, float scale, int in_size, int& i0, int& i1, float& w1) {
+    float s = ((float)d + 0.5f) * scale - 0.5f;
+    s = s < 0.0f ? 0.0f : s;
+    i0 = (int)s;
+    if (i0 > in_size - 1) i0 = in_size - 1;
+    i1 = i0 + (i0 < in_size - 1 ? 1 : 0);
+    w1 = s - (float)i0;
+}
+
+// Resample an NCHW fp32 map to (Ho, Wo) and emit CB8 bf16.  mode 0: bilinear (align_corners
+// False, scale = in/out), mode 1: legacy 'nearest' (src = floor(dst * in/out)).
+__global__ void plc_resize_nchw_to_cb8_kernel(const float* __restrict__ src, uint4* __restrict__ dst,
+                                              int N, int C, int Hi, int Wi, int Ho, int Wo, int mode,
+                                              float sh, float sw) {
+    const int ncb = (C + 7) / 8;
+    const long long hwo = (long long)Ho * Wo, hwi = (long long)Hi * Wi;
+    const long long total = (long long)N * ncb * hwo;
+    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const int ox = idx % Wo;
+        const int oy = (idx / Wo) % Ho;
+        const int cb = (idx / hwo) % ncb;
+        const long long n = idx / (hwo * ncb);
+        float v[8];
+        if (mode == 0) {
+            int y0, y1, x0, x1;
+            float wy, wx;
+            plc_bilinear_coord(oy, sh, Hi, y0, y1, wy);
+            plc_bilinear_coord(ox, sw, Wi, x0, x1, wx);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int c = 8 * cb + j;
+                if (c < C) {
+                    const float* p = src + (n * C + c) * hwi;
+                    const float a = p[(long long)y0 * Wi + x0], b = p[(long long)y0 * Wi + x1];
+                    const float cc = p[(long long)y1 * Wi + x0], d = p[(long long)y1 * Wi + x1];
+                    v[j] = (1.0f - wy) * ((1.0f - wx) * a + wx * b) + wy * ((1.0f - wx) * cc + wx * d);
+                } else v[j] = 0.0f;
+            }
+        } else {
+            int iy = (int)floorf((float)oy * sh), ix = (int)floorf((float)ox * sw);
+            iy = iy < Hi - 1 ? iy : Hi - 1;
+            ix = ix < Wi - 1 ? ix : Wi - 1;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int c = 8 * cb + j;
+                v[j] = c < C ? src[(n * C + c) * hwi + (long long)iy * Wi + ix] : 0.0f;
+            }
+        }
+        dst[idx] = make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7]));
+    }
+}
+
+// Bilinear (align_corners False) resample of a CB8 bf16 tensor [N][ncb][Hi][Wi] -> [N][ncb][Ho][Wo].
+__global__ void plc_resize_cb8_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, int N, int ncb,
+                                      int Hi, int Wi, int Ho, int Wo, float sh, float sw) {
+    const long long hwo = (long long)Ho * Wo, hwi = (long long)Hi * Wi;
+    const long long total = (long long)N * ncb * hwo;
+    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const int ox = idx % Wo;
+        const int oy = (idx / Wo) % Ho;
+        const long long plane = idx / hwo;
+        int y0, y1, x0, x1;
+        float wy, wx;
+        plc_bilinear_coord(oy, sh, Hi, y0, y1, wy);
+        plc_bilinear_coord(ox, sw, Wi, x0, x1, wx);
+        const uint4* p = src + plane * hwi;
+        const uint4 ua = p[(long long)y0 * Wi + x0], ub = p[(long long)y0 * Wi + x1];
+        const uint4 uc = p[(long long)y1 * Wi + x0], ud = p[(long long)y1 * Wi + x1];
+        const unsigned wa[4] = {ua.x, ua.y, ua.z, ua.w}, wb[4] = {ub.x, ub.y, ub.z, ub.w};
+        const unsigned wc[4] = {uc.x, uc.y, uc.z, uc.w}, wd[4] = {ud.x, ud.y, ud.z, ud.w};
+        unsigned o[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float r[2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int sft = 16 * e;
+                const float a = bf2f((unsigned short)(wa[k] >> sft)), b = bf2f((unsigned short)(wb[k] >> sft));
+                const float c = bf2f((unsigned short)(wc[k] >> sft)), d = bf2f((unsigned short)(wd[k] >> sft));
+                r[e] = (1.0f - wy) * ((1.0f - wx) * a + wx * b) + wy * ((1.0f - wx) * c + wx * d);
+            }
+            o[k] = pack_bf2(r[0], r[1]);
+        }
+        dst[idx] = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+}

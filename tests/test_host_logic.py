@@ -1,0 +1,81 @@
+"""CPU-side checks: the C-ABI library loads and exports every declared symbol, the host mirror keeps
+the reference's interface (state_dict keys, lazy blocks, geometry), and the product path refuses
+to run without a GPU (no CPU fallback)."""
+import os
+import re
+
+import pytest
+import torch
+
+from conftest import ROOT, master_params
+
+
+def test_library_exports_every_declared_symbol():
+    from pl_convlstm_gan_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "plconvlstm.h")).read()
+    declared = set(re.findall(r"\b(plc_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations found"
+    L = _lib.lib()
+    for name in sorted(declared):
+        assert hasattr(L, name), f"{name} declared in include/plconvlstm.h but not exported"
+    assert declared == set(_lib.EXPORTS)
+    assert L.plc_version() == 100
+
+
+def test_size_queries_without_gpu():
+    from pl_convlstm_gan_amd import _lib
+    L = _lib.lib()
+    # cell2 gate conv: 4 M tiles x 27 k-steps x 64 lanes x 16 B
+    assert L.plc_packed_weight_bytes(128, 16, 32, 3) == 4 * 27 * 64 * 16
+    assert L.plc_packed_weight_bytes(64, 16, 16, 3) == 2 * 18 * 64 * 16
+    assert L.plc_packed_bias_bytes(128) == 4 * 32 * 4
+    assert L.plc_convlstm_cell_workspace_bytes(2, 16, 32, 12, 12) > 0
+    assert L.plc_convlstm_cell_workspace_bytes(0, 16, 32, 12, 12) == 0
+
+
+def test_state_dict_matches_reference_names():
+    from pl_convlstm_gan_amd import Generator
+    from pl_convlstm_gan_amd.models import UpsampleBlock
+    m = Generator(hidden_dims=[16, 32], lu_channels=5, scale_factor=8)
+    assert m.upsample_blocks is None
+    ref = master_params(0)
+    sd = m.state_dict()
+    assert set(sd) == set(ref)
+    for k in ref:
+        assert tuple(sd[k].shape) == tuple(ref[k].shape), k
+    assert sum(p.numel() for p in m.parameters()) == 85889
+    m.upsample_blocks = torch.nn.ModuleList([UpsampleBlock(32, 2) for _ in range(3)])
+    m.load_state_dict(master_params(3), strict=True)
+    assert sum(p.numel() for p in m.parameters()) == 196865
+
+
+def test_geometry_and_lazy_blocks():
+    from pl_convlstm_gan_amd import Generator
+    for s, (nb, rem) in {1: (0, 1), 2: (1, 1.0), 3: (1, 1.5), 4: (2, 1.0), 6: (2, 1.5), 8: (3, 1.0)}.items():
+        m = Generator(hidden_dims=[16, 32], lu_channels=5, scale_factor=s)
+        n, r, fh, fw = m._geometry(32, 32, None, "cpu")
+        assert (n, r) == (nb, rem)
+        assert (fh, fw) == (32 * s, 32 * s)
+    m = Generator(hidden_dims=[16, 32], lu_channels=5, target_grid_size=(500, 500))
+    n, r, fh, fw = m._geometry(32, 32, (4000, 4000), "cpu")
+    assert (n, fh, fw) == (3, 256, 256) and m.target_size == (256, 256)
+
+
+def test_no_cpu_fallback():
+    from pl_convlstm_gan_amd import ConvLSTMCell, Generator
+    m = Generator(hidden_dims=[16, 32], lu_channels=5, scale_factor=1)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(torch.zeros(1, 1, 1, 8, 8), torch.zeros(1, 1, 8, 8), torch.zeros(1, 5, 8, 8))
+    c = ConvLSTMCell(16, 16)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        c(torch.zeros(1, 16, 8, 8), torch.zeros(1, 16, 8, 8), torch.zeros(1, 16, 8, 8))
+
+
+def test_drop_in_import_paths():
+    from src.models.attention import DEMAttention, LUAttention  # noqa: F401
+    from src.models.convlstm import ConvLSTMCell  # noqa: F401
+    from src.models.coordconv import add_coord_channels
+    from src.models.generator import Generator  # noqa: F401
+    y = add_coord_channels(torch.zeros(2, 1, 3, 4))
+    assert y.shape == (2, 3, 3, 4)
+    assert torch.equal(y[0, 1, :, 0], torch.linspace(0, 1, 3)) and torch.equal(y[0, 2, 0, :], torch.linspace(0, 1, 4))
