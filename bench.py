@@ -1,0 +1,189 @@
+#!/usr/bin/env python3
+"""Benchmark of the ConvLSTM rollout hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--mode fwd] [--config c3|c2|c1|p2]
+
+One "step" = one pass of the hot path (the Generator rollout) over one batch of synthetic,
+HBM-resident input.  The default workload is the per-GPU shard of BASELINE.json configs[2]
+(256x256 frames, T=10, global batch 32 on 8 GPUs = 4 per GPU, scale_factor=1): the batch is
+sharded over ranks with no data-path collective in the forward pass, so scaling is weak
+(per-GPU work fixed).  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CONFIGS = {
+    # name: (B per GPU, T, H, W, scale)   -- H, W are the LR grid; output is (H*scale, W*scale)
+    "c1": (2, 10, 64, 64, 1),      # BASELINE configs[0] shape (CPU plumbing case)
+    "c2": (8, 10, 128, 128, 1),    # configs[1]
+    "c3": (4, 10, 256, 256, 1),    # configs[2] per-GPU shard (the shape the metric is quoted on)
+    "c4": (4, 20, 256, 256, 1),    # configs[3] per-GPU shard (generator only)
+    "p2": (4, 10, 32, 32, 8),      # default.yaml-faithful x8 downscaling to 256x256
+}
+FLOP_PER_PX_FWD = 171104          # algorithmic forward FLOPs per output pixel per frame (scale 1, L=5)
+CELL2_FLOP_PER_PX = 2 * 55296     # cell-2 gate conv: (16+32)*9*128 MACs per pixel
+PEAK_BF16 = 2.5e15                # dense bf16 MFMA peak of MI355X, FLOP/s
+
+
+def synthetic(B, T, H, W, s, seed, device):
+    g = torch.Generator().manual_seed(seed)
+    rain = 10 * torch.rand(B, T, 1, H, W, generator=g) * (torch.rand(B, T, 1, H, W, generator=g) > 0.7)
+    dem = torch.rand(B, 1, H * s, W * s, generator=g)
+    lu = torch.nn.functional.one_hot(torch.randint(0, 5, (B, H * s, W * s), generator=g), 5)
+    lu = lu.permute(0, 3, 1, 2).float().contiguous()
+    return rain.to(device), dem.to(device), lu.to(device)
+
+
+def time_cell2_kernel(B, H, W, device, iters=50):
+    """Average duration of the dominant kernel (cell-2 gate conv + fused LSTM epilogue), measured
+    with events on the stream it is launched on."""
+    from pl_convlstm_gan_amd import _lib, ops
+    L = _lib.lib()
+    hw = H * W
+    x = torch.randint(-2 ** 15, 2 ** 15 - 1, (B * 2 * hw * 8,), dtype=torch.int16, device=device) & 0x3FFF
+    h = torch.randint(-2 ** 15, 2 ** 15 - 1, (B * 4 * hw * 8,), dtype=torch.int16, device=device) & 0x3FFF
+    c = torch.randn(B * 32 * hw, device=device)
+    w = 0.05 * torch.randn(128, 48, 3, 3, device=device)
+    b = torch.zeros(128, device=device)
+    wpk = torch.empty(L.plc_packed_weight_bytes(128, 16, 32, 3), dtype=torch.uint8, device=device)
+    bpk = torch.empty(L.plc_packed_bias_bytes(128), dtype=torch.uint8, device=device)
+    st = ops._stream()
+    _lib.check(L.plc_pack_conv_weight(w.data_ptr(), b.data_ptr(), wpk.data_ptr(), bpk.data_ptr(), 128, 16, 32, 3, 1, st), "pack")
+    ho = torch.empty_like(h)
+    co = torch.empty_like(c)
+
+    def run():
+        _lib.check(L.plc_convlstm_cell_fwd_cb8(x.data_ptr(), h.data_ptr(), c.data_ptr(), wpk.data_ptr(), bpk.data_ptr(),
+                                               ho.data_ptr(), co.data_ptr(), None, B, 16, 32, H, W, st), "cell2")
+    for _ in range(5):
+        run()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(iters):
+        run()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e-3 / iters
+
+
+def cpu_baseline(B, T, H, W, s, params):
+    """The CPU oracle (a port of the reference forward) timed on this host, best of 3."""
+    from oracle import cpu_oracle as O
+    threads = min(16, os.cpu_count() or 1)
+    torch.set_num_threads(threads)
+    rain, dem, lu = synthetic(B, T, H, W, s, 99, "cpu")
+    with torch.no_grad():
+        O.generator_forward(params, rain[:1, :1], dem[:1], lu[:1], scale_factor=s)
+        best = float("inf")
+        for _ in range(3):
+            t0 = time.perf_counter()
+            O.generator_forward(params, rain, dem, lu, scale_factor=s)
+            best = min(best, time.perf_counter() - t0)
+    return {"value": B * T / best, "unit": "frames/s", "cores": threads, "kind": "port",
+            "sample": f"full per-GPU workload B={B},T={T},{H * s}x{W * s}, fp32 PyTorch-CPU oracle forward, best of 3"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--mode", default="fwd", choices=["fwd"])
+    ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    from pl_convlstm_gan_amd import Generator
+    B, T, H, W, s = CONFIGS[args.config]
+    torch.manual_seed(0)
+    model = Generator(hidden_dims=[16, 32], lu_channels=5, scale_factor=s)
+    rain, dem, lu = synthetic(B, T, H, W, s, 1234 + rank, device)
+    model = model.to(device)
+    with torch.no_grad():
+        model(rain[:1, :1].contiguous(), dem[:1].contiguous(), lu[:1].contiguous())   # materialise lazy blocks
+
+    def step():
+        with torch.no_grad():
+            return model(rain, dem, lu)
+
+    for _ in range(args.warmup):
+        step()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    assert torch.isfinite(out).all()
+
+    if rank == 0:
+        frames = world * B * T * args.steps
+        ms = dt / args.steps * 1e3
+        res = {
+            "metric": "predicted frames/sec (whole node), BxTxCx256x256" if args.config in ("c3", "c4", "p2")
+                      else "predicted frames/sec (whole node)",
+            "value": frames / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"{args.config}: Generator rollout forward (inference), B={B}/GPU, T={T}, "
+                                   f"{H}x{W} -> {H * s}x{W * s}, 1 channel, hidden [16,32], L=5, scale_factor={s}",
+                       "global_batch": world * B, "T": T, "mode": args.mode,
+                       "parallelism": f"dp{world} (batch sharded, no forward collective)"},
+        }
+        # dominant kernel: cell-2 gate conv, one launch per timestep
+        tk = time_cell2_kernel(B, H, W, device)
+        flops = CELL2_FLOP_PER_PX * B * H * W
+        traffic = None
+        tj = os.path.join(ROOT, "profiles", "r1_cell2_traffic.json")
+        if os.path.exists(tj) and args.config == "c3":
+            traffic = json.load(open(tj)).get("hbm_bytes_per_launch")
+        res["roofline"] = {"bound": "mfma", "kernel": "plc_conv_mfma_kernel<2,4,4,3,CB8,LSTM> (cell-2 gate conv + LSTM epilogue)",
+                           "achieved": flops / tk / 1e12, "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
+                           "frac": flops / tk / PEAK_BF16, "traffic": traffic,
+                           "launch_us": tk * 1e6, "flop_per_launch": flops,
+                           "alg_bytes_per_launch": 416 * B * H * W,
+                           "hbm_frac": 416 * B * H * W / tk / 8e12}
+        if s == 1:
+            res["whole_path_tflops"] = frames / dt * FLOP_PER_PX_FWD * H * W / 1e12 / world
+        if not args.no_cpu_baseline and world == 1:
+            params = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+            res["cpu_baseline"] = cpu_baseline(B, T, H, W, s, params)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
