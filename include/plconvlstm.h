@@ -140,6 +140,49 @@ int plc_generator_rollout_fwd(const plc_rollout_desc* d, void* stream);
  * (size_t)-1 if unknown. */
 size_t plc_generator_workspace_offset(const plc_rollout_desc* d, const char* name);
 
+/* ---------------------------------------------------------------------------------------
+ * Backward passes.  The reference obtains them from autograd (loss.backward(),
+ * src/training/trainer.py:310); here they are explicit kernels: the pointwise LSTM backward,
+ * data-gradient convs (the forward kernel with transposed, tap-flipped weights) and
+ * weight-gradient GEMMs contracting over pixels.
+ *
+ * plc_convlstm_cell_bwd: gradients of ConvLSTMCell.forward (convlstm.py:16-28) given
+ *   dL/dh' (dh_next) and dL/dc' (dc_next); all tensors NCHW fp32; dweight [4Ch][Cin+Ch][3][3],
+ *   dbias [4Ch] (may be NULL) are overwritten.
+ * plc_generator_rollout_bwd: backpropagation through time over the rollout that
+ *   plc_generator_rollout_fwd ran with save_for_backward = 1 on the SAME descriptor (its
+ *   workspace holds the saved activations).  Writes the gradient of every parameter.
+ *   Not available (PLC_EUNSUPPORTED) when the rollout contains a bilinear feature resize.
+ * ------------------------------------------------------------------------------------- */
+size_t plc_convlstm_cell_bwd_workspace_bytes(int B, int Cin, int Ch, int H, int W);
+int plc_convlstm_cell_bwd(const float* x, const float* h, const float* c,
+                          const float* weight, const float* bias,
+                          const float* dh_next, const float* dc_next,
+                          float* dx, float* dh, float* dc, float* dweight, float* dbias,
+                          void* workspace, size_t workspace_bytes,
+                          int B, int Cin, int Ch, int H, int W, void* stream);
+
+typedef struct plc_rollout_grads {
+    const float* grad_out;   /* dL/d out, fp32 [B][T][1][out_H][out_W] */
+    /* parameter gradients (fp32, device, same shapes as the parameters; overwritten) */
+    float* init_w; float* init_b;
+    float* cell1_w; float* cell1_b;
+    float* cell2_w; float* cell2_b;
+    float* dem0_w; float* dem0_b;
+    float* dem2_w; float* dem2_b;
+    float* lu0_w; float* lu0_b;
+    float* lu2_w; float* lu2_b;
+    float* up_w[8]; float* up_b[8];
+    float* post0_w; float* post0_b;
+    float* post2_w; float* post2_b;
+    /* caller-owned scratch of plc_generator_bwd_workspace_bytes(desc) bytes, 256-byte aligned */
+    void* workspace;
+    size_t workspace_bytes;
+} plc_rollout_grads;
+
+size_t plc_generator_bwd_workspace_bytes(const plc_rollout_desc* d);
+int plc_generator_rollout_bwd(const plc_rollout_desc* d, const plc_rollout_grads* g, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -17,6 +17,8 @@ EXPORTS = (
     "plc_packed_weight_bytes", "plc_packed_bias_bytes", "plc_pack_conv_weight",
     "plc_convlstm_cell_fwd_cb8", "plc_convlstm_cell_workspace_bytes", "plc_convlstm_cell_fwd",
     "plc_generator_workspace_bytes", "plc_generator_rollout_fwd", "plc_generator_workspace_offset",
+    "plc_convlstm_cell_bwd_workspace_bytes", "plc_convlstm_cell_bwd",
+    "plc_generator_bwd_workspace_bytes", "plc_generator_rollout_bwd",
 )
 
 _f = C.c_void_p   # device pointers travel as plain addresses
@@ -39,6 +41,19 @@ class RolloutDesc(C.Structure):
         ("up_w", _f * 8), ("up_b", _f * 8),
         ("post0_w", _f), ("post0_b", _f), ("post2_w", _f), ("post2_b", _f),
         ("out", _f), ("workspace", _f), ("workspace_bytes", C.c_size_t),
+    ]
+
+
+class RolloutGrads(C.Structure):
+    """Mirror of ``plc_rollout_grads``."""
+    _fields_ = [
+        ("grad_out", _f),
+        ("init_w", _f), ("init_b", _f), ("cell1_w", _f), ("cell1_b", _f), ("cell2_w", _f), ("cell2_b", _f),
+        ("dem0_w", _f), ("dem0_b", _f), ("dem2_w", _f), ("dem2_b", _f),
+        ("lu0_w", _f), ("lu0_b", _f), ("lu2_w", _f), ("lu2_b", _f),
+        ("up_w", _f * 8), ("up_b", _f * 8),
+        ("post0_w", _f), ("post0_b", _f), ("post2_w", _f), ("post2_b", _f),
+        ("workspace", _f), ("workspace_bytes", C.c_size_t),
     ]
 
 
@@ -81,6 +96,14 @@ def lib():
     L.plc_generator_rollout_fwd.argtypes = [C.POINTER(RolloutDesc), p]
     L.plc_generator_workspace_offset.restype = sz
     L.plc_generator_workspace_offset.argtypes = [C.POINTER(RolloutDesc), C.c_char_p]
+    L.plc_convlstm_cell_bwd_workspace_bytes.restype = sz
+    L.plc_convlstm_cell_bwd_workspace_bytes.argtypes = [i, i, i, i, i]
+    L.plc_convlstm_cell_bwd.restype = i
+    L.plc_convlstm_cell_bwd.argtypes = [p] * 13 + [sz, i, i, i, i, i, p]
+    L.plc_generator_bwd_workspace_bytes.restype = sz
+    L.plc_generator_bwd_workspace_bytes.argtypes = [C.POINTER(RolloutDesc)]
+    L.plc_generator_rollout_bwd.restype = i
+    L.plc_generator_rollout_bwd.argtypes = [C.POINTER(RolloutDesc), C.POINTER(RolloutGrads), p]
     _lib = L
     return L
 

@@ -112,7 +112,24 @@ extern "C" int plc_pack_conv_weight(const float* w, const float* bias, void* wpk
     const int n_mt = pack_nmt(cout), nks = pack_nks(c0, c1, ks);
     const long long total = (long long)n_mt * nks * 512;
     hipLaunchKernelGGL(plc_pack_weight_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream,
-                       w, bias, (unsigned short*)wpk, bpk, cout, c0, c1, ks, mode, n_mt, nks, cout / 4);
+                       w, bias, (unsigned short*)wpk, bpk, cout, c0, c1, ks, mode, n_mt, nks, cout / 4, 0, 1);
+    PLC_HIP(hipGetLastError());
+    return PLC_OK;
+}
+
+// Data-gradient packing: rows = channels of the block-padded concat [c0 | c1], K = the cout output
+// channels split over `ksplit` waves.
+static inline int packT_nmt(int c0, int c1) { return cdiv(8 * pack_ncb(c0, c1), 32); }
+static inline int packT_nks(int cout, int ks, int ksplit) { return (ks * ks * (cdiv(cout, 8) / ksplit) + 1) / 2; }
+static size_t packedT_weight_bytes(int cout, int c0, int c1, int ks, int ksplit) {
+    return align256((size_t)packT_nmt(c0, c1) * ksplit * packT_nks(cout, ks, ksplit) * 64 * 16);
+}
+static int pack_conv_weight_T(const float* w, void* wpk, float* bpk, int cout, int c0, int c1, int ks, int ksplit,
+                              hipStream_t st) {
+    const int n_mt = packT_nmt(c0, c1), nks = packT_nks(cout, ks, ksplit);
+    const long long total = (long long)n_mt * ksplit * nks * 512;
+    hipLaunchKernelGGL(plc_pack_weight_kernel, dim3(ew_grid(total)), dim3(256), 0, st, w, (const float*)nullptr,
+                       (unsigned short*)wpk, bpk, cout, c0, c1, ks, 0, n_mt, nks, 0, 1, ksplit);
     PLC_HIP(hipGetLastError());
     return PLC_OK;
 }
@@ -128,22 +145,26 @@ static PlcTensor tens(const void* p, long long si, long long so) {
     return t;
 }
 
-template <int NCB0, int NCB1, int NMT, int KS, int STAGE, int EPI>
-static int launch_conv(ConvArgs a, int n_img, int n_mgroups, hipStream_t st) {
-    const int tx = cdiv(a.W, 32);
-    const long long t16 = (long long)n_img * cdiv(a.H, 16) * tx * n_mgroups;
-    a.tiles_x = tx;
-    if (t16 >= 512) {
-        a.tiles_y = cdiv(a.H, 16);
-        hipLaunchKernelGGL((plc_conv_mfma_kernel<NCB0, NCB1, NMT, KS, STAGE, EPI, 16>),
-                           dim3(n_img * a.tiles_x * a.tiles_y, n_mgroups), dim3(256), 0, st, a);
-    } else {
-        a.tiles_y = cdiv(a.H, 8);
-        hipLaunchKernelGGL((plc_conv_mfma_kernel<NCB0, NCB1, NMT, KS, STAGE, EPI, 8>),
-                           dim3(n_img * a.tiles_x * a.tiles_y, n_mgroups), dim3(256), 0, st, a);
-    }
+// One instantiation at a fixed tile height TH (and K split).
+template <int NCB0, int NCB1, int NMT, int KS, int STAGE, int EPI, int TH, int KSPLIT = 1>
+static int launch_conv_th(ConvArgs a, int n_img, int n_mgroups, hipStream_t st) {
+    constexpr int lds = plc_conv_lds_bytes<NCB0 + NCB1, KS, TH, KSPLIT>();
+    auto kern = plc_conv_mfma_kernel<NCB0, NCB1, NMT, KS, STAGE, EPI, TH, KSPLIT>;
+    if (lds > 65536)
+        PLC_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    a.tiles_x = cdiv(a.W, 32);
+    a.tiles_y = cdiv(a.H, TH);
+    hipLaunchKernelGGL(kern, dim3(n_img * a.tiles_x * a.tiles_y, n_mgroups), dim3(256), lds, st, a);
     PLC_HIP(hipGetLastError());
     return PLC_OK;
+}
+
+// 16-row tiles when that still yields at least two workgroups per CU, else 8-row tiles.
+template <int NCB0, int NCB1, int NMT, int KS, int STAGE, int EPI>
+static int launch_conv(ConvArgs a, int n_img, int n_mgroups, hipStream_t st) {
+    const long long t16 = (long long)n_img * cdiv(a.H, 16) * cdiv(a.W, 32) * n_mgroups;
+    if (t16 >= 512) return launch_conv_th<NCB0, NCB1, NMT, KS, STAGE, EPI, 16>(a, n_img, n_mgroups, st);
+    return launch_conv_th<NCB0, NCB1, NMT, KS, STAGE, EPI, 8>(a, n_img, n_mgroups, st);
 }
 
 static ConvArgs conv_args(int H, int W, int n_in) {
@@ -253,7 +274,7 @@ struct RolloutPlan {
     size_t xs, h1s, c1s, h2s, c2s, gates1, gates2;
     size_t up_out[8];   // output of upsample block k
     size_t mid, fin;    // after residual resize / after target resize (== previous stage if unused)
-    size_t dem_hr, lu_hr, dem_mid, lu_mid, gate_dem, gate, p0;
+    size_t dem_hr, lu_hr, dem_mid, lu_mid, gate_dem, gate_lu, gate, p0;
     size_t total;
     // derived sizes
     int up_H, up_W;     // size after the PixelShuffle blocks
@@ -325,6 +346,7 @@ static int rollout_plan(const plc_rollout_desc* d, RolloutPlan* p) {
     p->dem_mid = take((size_t)B * cdiv(C2 / 2, 8) * ohw * 16);
     p->lu_mid = take((size_t)B * cdiv(C2 / 2, 8) * ohw * 16);
     p->gate_dem = take((size_t)B * (C2 / 8) * ohw * 16);
+    p->gate_lu = d->save_for_backward ? take((size_t)B * (C2 / 8) * ohw * 16) : (size_t)-1;
     p->gate = take((size_t)B * (C2 / 8) * ohw * 16);
     p->p0 = take((size_t)T * B * 4 * ohw * 16);
     p->total = o;
@@ -434,6 +456,7 @@ extern "C" int plc_generator_rollout_fwd(const plc_rollout_desc* d, void* stream
         a.src0 = tens(ws + p.lu_mid, mcb * ohw * 16, 0);
         a.out0 = tens(ws + p.gate, (C2 / 8) * ohw * 16, 0);
         a.mul = tens(ws + p.gate_dem, (C2 / 8) * ohw * 16, 0);
+        if (d->save_for_backward) a.out1 = tens(ws + p.gate_lu, (C2 / 8) * ohw * 16, 0);
         a.wpk = (const uint4*)(ws + p.lu2.w);
         a.bpk = (const float*)(ws + p.lu2.b);
         a.act = ACT_SIGMOID;
@@ -528,3 +551,5 @@ extern "C" int plc_generator_rollout_fwd(const plc_rollout_desc* d, void* stream
     }
     return PLC_OK;
 }
+
+#include "plc_bwd_api.h"

@@ -1,0 +1,487 @@
+// Backward half of the C ABI (included at the end of plc_api.hip): weight-gradient launcher,
+// ConvLSTM cell backward, and backpropagation through time over the whole rollout.
+#pragma once
+#include "plc_bwd_kernels.h"
+#include "plc_wgrad_kernel.h"
+
+// fp32 single-channel plane per image (PlcTensor addressing) -> CB8 bf16 [N][1][H][W][8], channel 0
+__global__ void plc_plane_to_cb8_kernel(PlcTensor src, int n_in, int N, long long hw, uint4* __restrict__ dst) {
+    const long long total = (long long)N * hw;
+    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const int n = idx / hw;
+        const long long pix = idx % hw;
+        const float v = ((const float*)plc_img(src, n, n_in))[pix];
+        dst[idx] = make_uint4(pack_bf2(v, 0.0f), 0, 0, 0);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// weight gradient launcher
+// ---------------------------------------------------------------------------------------------
+static const int WGRAD_MAX_BLOCKS = 256;   // one persistent workgroup per CU
+
+template <int NCB0, int NCB1, int MT, int KS>
+static size_t wgrad_slab_bytes() {
+    using G = WgradGeom<NCB0 + NCB1, MT, KS>;
+    return align256((size_t)WGRAD_MAX_BLOCKS * (MT * 32) * (G::NT * 32) * sizeof(float));
+}
+
+// `in` carries H, W, n_in and the staging tensors of the conv input; dz has mcb_valid channel blocks.
+template <int NCB0, int NCB1, int MT, int KS, int STAGE>
+static int launch_wgrad(ConvArgs in, PlcTensor dz, int mcb_valid, int n_img, float* slab, size_t slab_bytes,
+                        float* dw, float* db, int cout, int c0, int c1, hipStream_t st) {
+    using G = WgradGeom<NCB0 + NCB1, MT, KS>;
+    if (slab_bytes < wgrad_slab_bytes<NCB0, NCB1, MT, KS>())
+        return plc_fail(PLC_EWORKSPACE, "wgrad: slab %zu < %zu bytes", slab_bytes, wgrad_slab_bytes<NCB0, NCB1, MT, KS>());
+    WgradArgs a;
+    memset(&a, 0, sizeof(a));
+    a.in = in;
+    a.in.tiles_x = cdiv(in.W, 32);
+    a.in.tiles_y = cdiv(in.H, WG_TH);
+    a.dz = dz;
+    a.mcb_valid = mcb_valid;
+    a.n_tiles = n_img * a.in.tiles_x * a.in.tiles_y;
+    a.slab = slab;
+    const int grid = a.n_tiles < WGRAD_MAX_BLOCKS ? a.n_tiles : WGRAD_MAX_BLOCKS;
+    auto kern = plc_wgrad_kernel<NCB0, NCB1, MT, KS, STAGE>;
+    PLC_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), G::LDS_BYTES, st, a);
+    PLC_HIP(hipGetLastError());
+    const long long total = (long long)cout * G::NT * 32;
+    hipLaunchKernelGGL(plc_wgrad_finalize_kernel, dim3(ew_grid(total)), dim3(256), 0, st, (const float*)slab, grid,
+                       MT * 32, G::NT * 32, dw, db, cout, c0, c1, KS, NCB0 + NCB1);
+    PLC_HIP(hipGetLastError());
+    return PLC_OK;
+}
+
+static Cb8View view(const void* p, long long img) {
+    Cb8View v;
+    v.p = (const char*)p;
+    v.img = img;
+    return v;
+}
+
+static int lstm_pointwise_bwd(Cb8View dh0, Cb8View dh1, Cb8View dh2, const void* dc_in, const void* gates,
+                              const void* c_prev, const void* c_cur, void* dz, void* dc_out, int B, int Ch, int H,
+                              int W, hipStream_t st) {
+    LstmBwdArgs a;
+    a.B = B; a.ncb = Ch / 8; a.H = H; a.W = W;
+    a.dh0 = dh0; a.dh1 = dh1; a.dh2 = dh2;
+    a.dc_in = (const char*)dc_in; a.gates = (const char*)gates;
+    a.c_prev = (const char*)c_prev; a.c_cur = (const char*)c_cur;
+    a.dz = (char*)dz; a.dc_out = (char*)dc_out;
+    const long long total = (long long)B * a.ncb * H * W;
+    hipLaunchKernelGGL(plc_lstm_pointwise_bwd_kernel, dim3(ew_grid(total)), dim3(256), 0, st, a);
+    PLC_HIP(hipGetLastError());
+    return PLC_OK;
+}
+
+// data gradient of a cell's gate conv: dz [B][4Ch/8] -> dcat [B][(Cin+Ch)/8] (bf16 CB8, [x | h] order)
+static int cell_dgrad(const void* dz, const void* wpkT, const float* bpk0, void* dcat, int B, int Cin, int Ch,
+                      int H, int W, hipStream_t st) {
+    const long long hw = (long long)H * W;
+    ConvArgs a = conv_args(H, W, B);
+    a.src0 = tens(dz, (4 * Ch / 8) * hw * 16, 0);
+    a.out0 = tens(dcat, ((Cin + Ch) / 8) * hw * 16, 0);
+    a.wpk = (const uint4*)wpkT;
+    a.bpk = bpk0;
+    a.act = ACT_NONE;
+    a.ncb_out = (Cin + Ch) / 8;
+    if (Cin == 16 && Ch == 16) return launch_conv_th<8, 0, 1, 3, STAGE_CB8, EPI_ACT_CB8, 8, 1>(a, B, 1, st);
+    if (Cin == 16 && Ch == 32) return launch_conv_th<16, 0, 2, 3, STAGE_CB8, EPI_ACT_CB8, 4, 2>(a, B, 1, st);
+    return plc_fail(PLC_EUNSUPPORTED, "ConvLSTM cell backward (Cin=%d, Ch=%d) is outside the compiled kernel set", Cin, Ch);
+}
+static int cell_dgrad_ksplit(int Cin, int Ch) { return (Cin == 16 && Ch == 32) ? 2 : 1; }
+
+static int cell_wgrad(const void* dz, PlcTensor x, PlcTensor h, int n_in, int n_img, float* slab, size_t slab_bytes,
+                      float* dw, float* db, int Cin, int Ch, int H, int W, hipStream_t st) {
+    const long long hw = (long long)H * W;
+    ConvArgs in = conv_args(H, W, n_in);
+    in.src0 = x;
+    in.src1 = h;
+    PlcTensor dzt = tens(dz, (4 * Ch / 8) * hw * 16, (long long)n_in * (4 * Ch / 8) * hw * 16);
+    if (Cin == 16 && Ch == 16)
+        return launch_wgrad<2, 2, 2, 3, STAGE_CB8>(in, dzt, 8, n_img, slab, slab_bytes, dw, db, 64, 16, 16, st);
+    if (Cin == 16 && Ch == 32)
+        return launch_wgrad<2, 4, 4, 3, STAGE_CB8>(in, dzt, 16, n_img, slab, slab_bytes, dw, db, 128, 16, 32, st);
+    return plc_fail(PLC_EUNSUPPORTED, "ConvLSTM cell backward (Cin=%d, Ch=%d) is outside the compiled kernel set", Cin, Ch);
+}
+static size_t cell_wgrad_slab_bytes(int Cin, int Ch) {
+    if (Cin == 16 && Ch == 16) return wgrad_slab_bytes<2, 2, 2, 3>();
+    return wgrad_slab_bytes<2, 4, 4, 3>();
+}
+
+// ---------------------------------------------------------------------------------------------
+// ConvLSTM cell backward on boundary-layout tensors
+// ---------------------------------------------------------------------------------------------
+struct CellBwdWs {
+    CellWs f;                 // forward carve (x, h, c, wpk, bpk, ho, co)
+    size_t gates, wpkT, bpk0, dh8, dz, dcat, dc, slab, total;
+};
+static CellBwdWs cell_bwd_ws(int B, int Cin, int Ch, int H, int W) {
+    CellBwdWs s;
+    s.f = cell_ws(B, Cin, Ch, H, W);
+    const size_t hw = (size_t)H * W;
+    size_t o = s.f.total;
+    auto take = [&](size_t bytes) { size_t at = o; o += align256(bytes); return at; };
+    s.gates = take((size_t)B * (4 * Ch / 8) * hw * 16);
+    s.wpkT = take(packedT_weight_bytes(4 * Ch, Cin, Ch, 3, cell_dgrad_ksplit(Cin, Ch)));
+    s.bpk0 = take((size_t)packT_nmt(Cin, Ch) * 32 * sizeof(float));
+    s.dh8 = take((size_t)B * (Ch / 8) * hw * 16);
+    s.dz = take((size_t)B * (4 * Ch / 8) * hw * 16);
+    s.dcat = take((size_t)B * ((Cin + Ch) / 8) * hw * 16);
+    s.dc = take((size_t)B * (Ch / 8) * hw * 32 * 2);
+    s.slab = take(cell_wgrad_slab_bytes(Cin, Ch));
+    s.total = o;
+    return s;
+}
+
+extern "C" size_t plc_convlstm_cell_bwd_workspace_bytes(int B, int Cin, int Ch, int H, int W) {
+    if (B <= 0 || Cin <= 0 || Ch <= 0 || H <= 0 || W <= 0) return 0;
+    return cell_bwd_ws(B, Cin, Ch, H, W).total;
+}
+
+extern "C" int plc_convlstm_cell_bwd(const float* x, const float* h, const float* c, const float* weight,
+                                     const float* bias, const float* dh_next, const float* dc_next, float* dx,
+                                     float* dh, float* dc, float* dweight, float* dbias, void* workspace,
+                                     size_t workspace_bytes, int B, int Cin, int Ch, int H, int W, void* stream) {
+    PLC_REQUIRE(x && h && c && weight && dh_next && dc_next && dx && dh && dc && dweight && workspace,
+                "plc_convlstm_cell_bwd: null pointer");
+    PLC_REQUIRE(B > 0 && H > 0 && W > 0, "plc_convlstm_cell_bwd: non-positive size");
+    PLC_REQUIRE(((uintptr_t)workspace & 255) == 0, "plc_convlstm_cell_bwd: workspace must be 256-byte aligned");
+    if (!((Cin == 16 && Ch == 16) || (Cin == 16 && Ch == 32)))
+        return plc_fail(PLC_EUNSUPPORTED,
+                        "ConvLSTM cell (Cin=%d, Ch=%d) is outside the compiled kernel set {(16,16), (16,32)}", Cin, Ch);
+    const CellBwdWs s = cell_bwd_ws(B, Cin, Ch, H, W);
+    if (workspace_bytes < s.total)
+        return plc_fail(PLC_EWORKSPACE, "plc_convlstm_cell_bwd: workspace %zu < %zu bytes", workspace_bytes, s.total);
+    hipStream_t st = (hipStream_t)stream;
+    char* ws = (char*)workspace;
+    const long long hw = (long long)H * W;
+    int rc;
+    // recompute the forward to obtain the gate activations
+    if ((rc = plc_nchw_f32_to_cb8_bf16(x, ws + s.f.x, B, Cin, H, W, stream))) return rc;
+    if ((rc = plc_nchw_f32_to_cb8_bf16(h, ws + s.f.h, B, Ch, H, W, stream))) return rc;
+    if ((rc = plc_nchw_f32_to_cb8_f32(c, (float*)(ws + s.f.c), B, Ch, H, W, stream))) return rc;
+    if ((rc = plc_pack_conv_weight(weight, bias, ws + s.f.wpk, (float*)(ws + s.f.bpk), 4 * Ch, Cin, Ch, 3,
+                                   PLC_PACK_LSTM, stream)))
+        return rc;
+    if ((rc = cell_fwd_cb8(ws + s.f.x, ws + s.f.h, (float*)(ws + s.f.c), ws + s.f.wpk, (float*)(ws + s.f.bpk),
+                           ws + s.f.ho, (float*)(ws + s.f.co), ws + s.gates, B, Cin, Ch, H, W, st)))
+        return rc;
+    // pointwise backward
+    if ((rc = plc_nchw_f32_to_cb8_bf16(dh_next, ws + s.dh8, B, Ch, H, W, stream))) return rc;
+    float* dc_in = (float*)(ws + s.dc);
+    float* dc_out = (float*)(ws + s.dc + (size_t)B * (Ch / 8) * hw * 32);
+    if ((rc = plc_nchw_f32_to_cb8_f32(dc_next, dc_in, B, Ch, H, W, stream))) return rc;
+    if ((rc = lstm_pointwise_bwd(view(ws + s.dh8, (Ch / 8) * hw * 16), view(nullptr, 0), view(nullptr, 0), dc_in,
+                                 ws + s.gates, ws + s.f.c, ws + s.f.co, ws + s.dz, dc_out, B, Ch, H, W, st)))
+        return rc;
+    // data gradient
+    if ((rc = pack_conv_weight_T(weight, ws + s.wpkT, (float*)(ws + s.bpk0), 4 * Ch, Cin, Ch, 3,
+                                 cell_dgrad_ksplit(Cin, Ch), st)))
+        return rc;
+    if ((rc = cell_dgrad(ws + s.dz, ws + s.wpkT, (const float*)(ws + s.bpk0), ws + s.dcat, B, Cin, Ch, H, W, st)))
+        return rc;
+    // weight gradient
+    if ((rc = cell_wgrad(ws + s.dz, tens(ws + s.f.x, (Cin / 8) * hw * 16, 0), tens(ws + s.f.h, (Ch / 8) * hw * 16, 0),
+                         B, B, (float*)(ws + s.slab), cell_wgrad_slab_bytes(Cin, Ch), dweight, dbias, Cin, Ch, H, W, st)))
+        return rc;
+    // back to the boundary layout: dcat = [dx (Cin) | dh (Ch)] per image
+    {
+        const long long cat_img = ((Cin + Ch) / 8) * hw * 16;
+        // dx / dh are strided views of dcat: convert image by image through the generic kernel
+        for (int b = 0; b < B; ++b) {
+            if ((rc = plc_cb8_bf16_to_nchw_f32(ws + s.dcat + b * cat_img, dx + (long long)b * Cin * hw, 1, Cin, H, W, stream)))
+                return rc;
+            if ((rc = plc_cb8_bf16_to_nchw_f32(ws + s.dcat + b * cat_img + (Cin / 8) * hw * 16, dh + (long long)b * Ch * hw,
+                                               1, Ch, H, W, stream)))
+                return rc;
+        }
+    }
+    if ((rc = plc_cb8_f32_to_nchw_f32(dc_out, dc, B, Ch, H, W, stream))) return rc;
+    return PLC_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Generator rollout backward (BPTT)
+// ---------------------------------------------------------------------------------------------
+struct BwdPlan {
+    size_t post2T, post0T, cell1T, cell2T, lu2T, dem2T, upT[8], bpk0;
+    size_t d_out8, d_pre0, d_feat, d_pre, d_lu_pre, d_dem_pre, d_lu_mid, d_dem_mid;
+    size_t d_conv[8], d_in[8];
+    size_t dz1, dz2, dcat1, dcat2, dc1, dc2, d_pre_init, slab, slab_bytes, total;
+};
+
+static size_t max_sz(size_t a, size_t b) { return a > b ? a : b; }
+
+static int bwd_plan(const plc_rollout_desc* d, const RolloutPlan& fp, BwdPlan* p) {
+    const int C1 = d->C1, C2 = d->C2, B = d->B, T = d->T, NI = d->B * d->T;
+    const size_t hw = (size_t)d->H * d->W, ohw = (size_t)d->out_H * d->out_W;
+    if (d->mid_H != fp.up_H || d->mid_W != fp.up_W || d->out_H != d->mid_H || d->out_W != d->mid_W)
+        return plc_fail(PLC_EUNSUPPORTED,
+                        "rollout backward: the bilinear feature resize (non power-of-two scale / target_size) "
+                        "has no backward kernel yet");
+    size_t o = 0;
+    auto take = [&](size_t bytes) { size_t at = o; o += align256(bytes); return at; };
+    p->post2T = take(packedT_weight_bytes(1, 32, 0, 3, 1));
+    p->post0T = take(packedT_weight_bytes(32, C2, 0, 3, 1));
+    p->cell1T = take(packedT_weight_bytes(4 * C1, C1, C1, 3, 1));
+    p->cell2T = take(packedT_weight_bytes(4 * C2, C1, C2, 3, 2));
+    p->lu2T = take(packedT_weight_bytes(C2, C2 / 2, 0, 1, 1));
+    p->dem2T = take(packedT_weight_bytes(C2, C2 / 2, 0, 1, 1));
+    for (int k = 0; k < d->n_blocks; ++k) p->upT[k] = take(packedT_weight_bytes(4 * C2, C2, 0, 3, 2));
+    p->bpk0 = take(8 * 32 * sizeof(float));
+    p->d_out8 = take((size_t)NI * ohw * 16);
+    p->d_pre0 = take((size_t)NI * 4 * ohw * 16);
+    p->d_feat = take((size_t)NI * (C2 / 8) * ohw * 16);
+    p->d_pre = take((size_t)NI * (C2 / 8) * ohw * 16);
+    p->d_lu_pre = take((size_t)B * (C2 / 8) * ohw * 16);
+    p->d_dem_pre = take((size_t)B * (C2 / 8) * ohw * 16);
+    p->d_lu_mid = take((size_t)B * cdiv(C2 / 2, 8) * ohw * 16);
+    p->d_dem_mid = take((size_t)B * cdiv(C2 / 2, 8) * ohw * 16);
+    for (int k = 0; k < d->n_blocks; ++k) {
+        const size_t s = (size_t)(d->H << k) * (d->W << k);
+        p->d_conv[k] = take((size_t)NI * (4 * C2 / 8) * s * 16);
+        p->d_in[k] = take((size_t)NI * (C2 / 8) * s * 16);
+    }
+    p->dz1 = take((size_t)NI * (4 * C1 / 8) * hw * 16);
+    p->dz2 = take((size_t)NI * (4 * C2 / 8) * hw * 16);
+    p->dcat1 = take((size_t)NI * (2 * C1 / 8) * hw * 16);
+    p->dcat2 = take((size_t)2 * B * ((C1 + C2) / 8) * hw * 16);
+    p->dc1 = take((size_t)2 * B * (C1 / 8) * hw * 32);
+    p->dc2 = take((size_t)2 * B * (C2 / 8) * hw * 32);
+    p->d_pre_init = take((size_t)NI * (C1 / 8) * hw * 16);
+    size_t sb = wgrad_slab_bytes<2, 4, 4, 3>();
+    sb = max_sz(sb, wgrad_slab_bytes<2, 2, 2, 3>());
+    sb = max_sz(sb, wgrad_slab_bytes<4, 0, 1, 3>());
+    sb = max_sz(sb, wgrad_slab_bytes<4, 0, 4, 3>());
+    sb = max_sz(sb, wgrad_slab_bytes<2, 0, 1, 3>());
+    sb = max_sz(sb, wgrad_slab_bytes<1, 0, 1, 3>());
+    sb = max_sz(sb, wgrad_slab_bytes<2, 0, 1, 1>());
+    p->slab_bytes = sb;
+    p->slab = take(sb);
+    p->total = o;
+    (void)T;
+    return PLC_OK;
+}
+
+extern "C" size_t plc_generator_bwd_workspace_bytes(const plc_rollout_desc* d) {
+    RolloutPlan fp;
+    BwdPlan bp;
+    if (rollout_plan(d, &fp) != PLC_OK) return 0;
+    if (bwd_plan(d, fp, &bp) != PLC_OK) return 0;
+    return bp.total;
+}
+
+extern "C" int plc_generator_rollout_bwd(const plc_rollout_desc* d, const plc_rollout_grads* g, void* stream) {
+    RolloutPlan fp;
+    BwdPlan bp;
+    int rc = rollout_plan(d, &fp);
+    if (rc) return rc;
+    PLC_REQUIRE(g, "rollout backward: null gradient descriptor");
+    PLC_REQUIRE(d->save_for_backward, "rollout backward: the forward pass was run without save_for_backward");
+    if ((rc = bwd_plan(d, fp, &bp))) return rc;
+    PLC_REQUIRE(g->grad_out && g->workspace && d->workspace && d->rain && d->row_tab && d->col_tab,
+                "rollout backward: null tensor pointer");
+    PLC_REQUIRE(g->init_w && g->init_b && g->cell1_w && g->cell1_b && g->cell2_w && g->cell2_b && g->dem0_w &&
+                    g->dem0_b && g->dem2_w && g->dem2_b && g->lu0_w && g->lu0_b && g->lu2_w && g->lu2_b &&
+                    g->post0_w && g->post0_b && g->post2_w && g->post2_b,
+                "rollout backward: null gradient pointer");
+    for (int k = 0; k < d->n_blocks; ++k) PLC_REQUIRE(g->up_w[k] && g->up_b[k], "rollout backward: null upsample gradient %d", k);
+    PLC_REQUIRE(((uintptr_t)g->workspace & 255) == 0, "rollout backward: workspace must be 256-byte aligned");
+    if (g->workspace_bytes < bp.total)
+        return plc_fail(PLC_EWORKSPACE, "rollout backward: workspace %zu < %zu bytes", g->workspace_bytes, bp.total);
+    if (d->workspace_bytes < fp.total)
+        return plc_fail(PLC_EWORKSPACE, "rollout backward: forward workspace %zu < %zu bytes", d->workspace_bytes, fp.total);
+
+    hipStream_t st = (hipStream_t)stream;
+    char* wf = (char*)d->workspace;   // forward workspace: saved activations
+    char* wb = (char*)g->workspace;   // backward scratch
+    const int B = d->B, T = d->T, H = d->H, W = d->W, C1 = d->C1, C2 = d->C2, L = d->L, NI = B * T;
+    const int oH = d->out_H, oW = d->out_W;
+    const long long hw = (long long)H * W, ohw = (long long)oH * oW;
+    float* slab = (float*)(wb + bp.slab);
+    const float* bpk0 = (const float*)(wb + bp.bpk0);
+    const int mcb = cdiv(C2 / 2, 8);
+    const long long fimg = (C2 / 8) * ohw * 16;   // one C2-channel image at output resolution
+
+    PLC_HIP(hipMemsetAsync(wb + bp.bpk0, 0, 8 * 32 * sizeof(float), st));
+    // ---- transposed (data-gradient) weights -------------------------------------------------
+    if ((rc = pack_conv_weight_T(d->post2_w, wb + bp.post2T, nullptr, 1, 32, 0, 3, 1, st))) return rc;
+    if ((rc = pack_conv_weight_T(d->post0_w, wb + bp.post0T, nullptr, 32, C2, 0, 3, 1, st))) return rc;
+    if ((rc = pack_conv_weight_T(d->cell1_w, wb + bp.cell1T, nullptr, 4 * C1, C1, C1, 3, 1, st))) return rc;
+    if ((rc = pack_conv_weight_T(d->cell2_w, wb + bp.cell2T, nullptr, 4 * C2, C1, C2, 3, 2, st))) return rc;
+    if ((rc = pack_conv_weight_T(d->lu2_w, wb + bp.lu2T, nullptr, C2, C2 / 2, 0, 1, 1, st))) return rc;
+    if ((rc = pack_conv_weight_T(d->dem2_w, wb + bp.dem2T, nullptr, C2, C2 / 2, 0, 1, 1, st))) return rc;
+    for (int k = 0; k < d->n_blocks; ++k)
+        if ((rc = pack_conv_weight_T(d->up_w[k], wb + bp.upT[k], nullptr, 4 * C2, C2, 0, 3, 2, st))) return rc;
+
+    // ---- output convs -------------------------------------------------------------------------
+    const PlcTensor gout = tens(g->grad_out, (long long)T * ohw * 4, ohw * 4);   // n = t*B + b -> grad_out[b][t]
+    hipLaunchKernelGGL(plc_plane_to_cb8_kernel, dim3(ew_grid((long long)NI * ohw)), dim3(256), 0, st, gout, B, NI,
+                       ohw, (uint4*)(wb + bp.d_out8));
+    PLC_HIP(hipGetLastError());
+    {
+        ConvArgs in = conv_args(oH, oW, B);
+        in.src0 = tens(wf + fp.p0, 4 * ohw * 16, (long long)B * 4 * ohw * 16);
+        if ((rc = launch_wgrad<4, 0, 1, 3, STAGE_CB8>(in, tens(wb + bp.d_out8, ohw * 16, (long long)B * ohw * 16), 1, NI,
+                                                      slab, bp.slab_bytes, g->post2_w, g->post2_b, 1, 32, 0, st)))
+            return rc;
+        ConvArgs a = conv_args(oH, oW, B);
+        a.src0 = gout;
+        a.out0 = tens(wb + bp.d_pre0, 4 * ohw * 16, (long long)B * 4 * ohw * 16);
+        a.mul = tens(wf + fp.p0, 4 * ohw * 16, (long long)B * 4 * ohw * 16);
+        a.mul_mode = MUL_RELU_MASK;
+        a.wpk = (const uint4*)(wb + bp.post2T);
+        a.bpk = bpk0;
+        a.ncb_out = 4;
+        if ((rc = launch_conv<1, 0, 1, 3, STAGE_F32_1CH, EPI_ACT_CB8>(a, NI, 1, st))) return rc;
+
+        in = conv_args(oH, oW, B);
+        in.src0 = tens(wf + fp.fin, fimg, (long long)B * fimg);
+        in.gate = tens(wf + fp.gate, fimg, 0);
+        if ((rc = launch_wgrad<4, 0, 1, 3, STAGE_CB8_GATED>(in, tens(wb + bp.d_pre0, 4 * ohw * 16, (long long)B * 4 * ohw * 16),
+                                                            4, NI, slab, bp.slab_bytes, g->post0_w, g->post0_b, 32, C2, 0, st)))
+            return rc;
+        a = conv_args(oH, oW, B);
+        a.src0 = tens(wb + bp.d_pre0, 4 * ohw * 16, (long long)B * 4 * ohw * 16);
+        a.out0 = tens(wb + bp.d_feat, fimg, (long long)B * fimg);
+        a.wpk = (const uint4*)(wb + bp.post0T);
+        a.bpk = bpk0;
+        a.ncb_out = C2 / 8;
+        if ((rc = launch_conv<4, 0, 1, 3, STAGE_CB8, EPI_ACT_CB8>(a, NI, 1, st))) return rc;
+    }
+    // ---- gating and the two attention branches ------------------------------------------------
+    {
+        GateBwdArgs ga;
+        ga.B = B; ga.T = T; ga.ncb = C2 / 8; ga.H = oH; ga.W = oW;
+        ga.d_feat = wb + bp.d_feat;
+        ga.feat_pre = wf + fp.fin;
+        ga.gate = wf + fp.gate;
+        ga.gate_dem = wf + fp.gate_dem;
+        ga.gate_lu = wf + fp.gate_lu;
+        ga.d_pre = wb + bp.d_pre;
+        ga.d_lu_pre = wb + bp.d_lu_pre;
+        ga.d_dem_pre = wb + bp.d_dem_pre;
+        hipLaunchKernelGGL(plc_gate_bwd_kernel, dim3(ew_grid((long long)B * (C2 / 8) * ohw)), dim3(256), 0, st, ga);
+        PLC_HIP(hipGetLastError());
+
+        struct Branch {
+            size_t d_pre, d_mid, mid, hr, w2T;
+            const float* w0; float *g0w, *g0b, *g2w, *g2b;
+            int cin;
+        };
+        const Branch br[2] = {
+            {bp.d_lu_pre, bp.d_lu_mid, fp.lu_mid, fp.lu_hr, bp.lu2T, d->lu0_w, g->lu0_w, g->lu0_b, g->lu2_w, g->lu2_b, L},
+            {bp.d_dem_pre, bp.d_dem_mid, fp.dem_mid, fp.dem_hr, bp.dem2T, d->dem0_w, g->dem0_w, g->dem0_b, g->dem2_w, g->dem2_b, 1},
+        };
+        for (int i = 0; i < 2; ++i) {
+            const Branch& q = br[i];
+            // 1x1 conv (C2/2 -> C2): weight gradient, then data gradient masked by the ReLU of the 3x3 conv
+            ConvArgs in = conv_args(oH, oW, B);
+            in.src0 = tens(wf + q.mid, mcb * ohw * 16, 0);
+            if ((rc = launch_wgrad<2, 0, 1, 1, STAGE_CB8>(in, tens(wb + q.d_pre, fimg, 0), C2 / 8, B, slab, bp.slab_bytes,
+                                                          q.g2w, q.g2b, C2, C2 / 2, 0, st)))
+                return rc;
+            ConvArgs a = conv_args(oH, oW, B);
+            a.src0 = tens(wb + q.d_pre, fimg, 0);
+            a.out0 = tens(wb + q.d_mid, mcb * ohw * 16, 0);
+            a.mul = tens(wf + q.mid, mcb * ohw * 16, 0);
+            a.mul_mode = MUL_RELU_MASK;
+            a.wpk = (const uint4*)(wb + q.w2T);
+            a.bpk = bpk0;
+            a.ncb_out = mcb;
+            if ((rc = launch_conv<4, 0, 1, 1, STAGE_CB8, EPI_ACT_CB8>(a, B, 1, st))) return rc;
+            // 3x3 conv (aux -> C2/2): weight gradient only (the aux maps need no gradient)
+            in = conv_args(oH, oW, B);
+            in.src0 = tens(wf + q.hr, cdiv(q.cin, 8) * ohw * 16, 0);
+            if (q.cin <= 8)
+                rc = launch_wgrad<1, 0, 1, 3, STAGE_CB8>(in, tens(wb + q.d_mid, mcb * ohw * 16, 0), mcb, B, slab,
+                                                         bp.slab_bytes, q.g0w, q.g0b, C2 / 2, q.cin, 0, st);
+            else
+                rc = launch_wgrad<2, 0, 1, 3, STAGE_CB8>(in, tens(wb + q.d_mid, mcb * ohw * 16, 0), mcb, B, slab,
+                                                         bp.slab_bytes, q.g0w, q.g0b, C2 / 2, q.cin, 0, st);
+            if (rc) return rc;
+        }
+    }
+    // ---- PixelShuffle upsample blocks, last to first ------------------------------------------
+    const char* cur = wb + bp.d_pre;     // gradient of the feature map entering the gates
+    for (int k = d->n_blocks - 1; k >= 0; --k) {
+        const int kh = H << k, kw = W << k;
+        const long long khw = (long long)kh * kw;
+        const char* in_k = (k == 0) ? wf + fp.h2s + (size_t)B * fp.img2 : wf + fp.up_out[k - 1];
+        hipLaunchKernelGGL(plc_pixel_unshuffle_mask_kernel, dim3(ew_grid((long long)NI * (4 * C2 / 8) * khw)), dim3(256),
+                           0, st, cur, (const char*)(wf + fp.up_out[k]), wb + bp.d_conv[k], NI, C2, kh, kw);
+        PLC_HIP(hipGetLastError());
+        ConvArgs in = conv_args(kh, kw, NI);
+        in.src0 = tens(in_k, (C2 / 8) * khw * 16, 0);
+        if ((rc = launch_wgrad<4, 0, 4, 3, STAGE_CB8>(in, tens(wb + bp.d_conv[k], (4 * C2 / 8) * khw * 16, 0), 4 * C2 / 8,
+                                                      NI, slab, bp.slab_bytes, g->up_w[k], g->up_b[k], 4 * C2, C2, 0, st)))
+            return rc;
+        ConvArgs a = conv_args(kh, kw, NI);
+        a.src0 = tens(wb + bp.d_conv[k], (4 * C2 / 8) * khw * 16, 0);
+        a.out0 = tens(wb + bp.d_in[k], (C2 / 8) * khw * 16, 0);
+        a.wpk = (const uint4*)(wb + bp.upT[k]);
+        a.bpk = bpk0;
+        a.ncb_out = C2 / 8;
+        if ((rc = launch_conv_th<16, 0, 1, 3, STAGE_CB8, EPI_ACT_CB8, 4, 2>(a, NI, 1, st))) return rc;
+        cur = wb + bp.d_in[k];
+    }
+    // ---- backpropagation through time ---------------------------------------------------------
+    const size_t s1 = (size_t)B * fp.img1, s2 = (size_t)B * fp.img2;      // bytes of one step (bf16 CB8)
+    const size_t cat1 = (size_t)(2 * C1 / 8) * hw * 16, cat2 = (size_t)((C1 + C2) / 8) * hw * 16;
+    const size_t plane = (size_t)hw * 16;
+    for (int t = T - 1; t >= 0; --t) {
+        const bool last = (t == T - 1);
+        char* dcat2_t = wb + bp.dcat2 + (size_t)(t & 1) * B * cat2;
+        const char* dcat2_n = wb + bp.dcat2 + (size_t)((t + 1) & 1) * B * cat2;
+        char* dc2_t = wb + bp.dc2 + (size_t)(t & 1) * s2 * 2;
+        const char* dc2_n = wb + bp.dc2 + (size_t)((t + 1) & 1) * s2 * 2;
+        char* dz2_t = wb + bp.dz2 + (size_t)t * s2 * 4;
+        if ((rc = lstm_pointwise_bwd(view(cur + (size_t)t * s2, fp.img2),
+                                     last ? view(nullptr, 0) : view(dcat2_n + (C1 / 8) * plane, cat2), view(nullptr, 0),
+                                     last ? nullptr : dc2_n, wf + fp.gates2 + (size_t)t * s2 * 4,
+                                     wf + fp.c2s + (size_t)t * s2 * 2, wf + fp.c2s + (size_t)(t + 1) * s2 * 2, dz2_t,
+                                     dc2_t, B, C2, H, W, st)))
+            return rc;
+        if ((rc = cell_dgrad(dz2_t, wb + bp.cell2T, bpk0, dcat2_t, B, C1, C2, H, W, st))) return rc;
+
+        char* dcat1_t = wb + bp.dcat1 + (size_t)t * B * cat1;
+        const char* dcat1_n = wb + bp.dcat1 + (size_t)(t + 1) * B * cat1;
+        char* dc1_t = wb + bp.dc1 + (size_t)(t & 1) * s1 * 2;
+        const char* dc1_n = wb + bp.dc1 + (size_t)((t + 1) & 1) * s1 * 2;
+        char* dz1_t = wb + bp.dz1 + (size_t)t * s1 * 4;
+        if ((rc = lstm_pointwise_bwd(view(dcat2_t, cat2), last ? view(nullptr, 0) : view(dcat1_n + (C1 / 8) * plane, cat1),
+                                     view(nullptr, 0), last ? nullptr : dc1_n, wf + fp.gates1 + (size_t)t * s1 * 4,
+                                     wf + fp.c1s + (size_t)t * s1 * 2, wf + fp.c1s + (size_t)(t + 1) * s1 * 2, dz1_t,
+                                     dc1_t, B, C1, H, W, st)))
+            return rc;
+        if ((rc = cell_dgrad(dz1_t, wb + bp.cell1T, bpk0, dcat1_t, B, C1, C1, H, W, st))) return rc;
+    }
+    // ---- stem: gradient through the ReLU, then the weight gradient ----------------------------
+    hipLaunchKernelGGL(plc_relu_mask_kernel, dim3(ew_grid((long long)NI * (C1 / 8) * hw)), dim3(256), 0, st,
+                       view(wb + bp.dcat1, cat1), view(wf + fp.xs, fp.img1), wb + bp.d_pre_init, (long long)fp.img1, NI,
+                       C1 / 8, hw);
+    PLC_HIP(hipGetLastError());
+    {
+        ConvArgs in = conv_args(H, W, B);
+        in.src0 = tens(d->rain, (long long)T * hw * 4, hw * 4);
+        in.row_tab = d->row_tab;
+        in.col_tab = d->col_tab;
+        if ((rc = launch_wgrad<1, 0, 1, 3, STAGE_COORD>(in, tens(wb + bp.d_pre_init, fp.img1, (long long)B * fp.img1),
+                                                        C1 / 8, NI, slab, bp.slab_bytes, g->init_w, g->init_b, C1, 3, 0, st)))
+            return rc;
+    }
+    // ---- gate-conv weight gradients, batched over all T*B frames -------------------------------
+    if ((rc = cell_wgrad(wb + bp.dz2, tens(wf + fp.h1s + s1, fp.img1, (long long)B * fp.img1),
+                         tens(wf + fp.h2s, fp.img2, (long long)B * fp.img2), B, NI, slab, bp.slab_bytes, g->cell2_w,
+                         g->cell2_b, C1, C2, H, W, st)))
+        return rc;
+    if ((rc = cell_wgrad(wb + bp.dz1, tens(wf + fp.xs, fp.img1, (long long)B * fp.img1),
+                         tens(wf + fp.h1s, fp.img1, (long long)B * fp.img1), B, NI, slab, bp.slab_bytes, g->cell1_w,
+                         g->cell1_b, C1, C1, H, W, st)))
+        return rc;
+    return PLC_OK;
+}

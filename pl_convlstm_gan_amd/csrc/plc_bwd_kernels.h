@@ -1,0 +1,202 @@
+// Pointwise pieces of the backward pass (HBM-bound, one pass each) on CB8 tensors.
+// One thread handles one 16-byte unit = 8 channels of one pixel.
+#pragma once
+#include "plc_common.h"
+
+struct F8 {
+    float v[8];
+};
+__device__ __forceinline__ F8 ld_bf8(const char* p) {
+    const uint4 u = *(const uint4*)p;
+    const float4 a = unpack_bf4(make_uint2(u.x, u.y)), b = unpack_bf4(make_uint2(u.z, u.w));
+    F8 r;
+    r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = a.w;
+    r.v[4] = b.x; r.v[5] = b.y; r.v[6] = b.z; r.v[7] = b.w;
+    return r;
+}
+__device__ __forceinline__ void st_bf8(char* p, const F8& f) {
+    *(uint4*)p = make_uint4(pack_bf2(f.v[0], f.v[1]), pack_bf2(f.v[2], f.v[3]), pack_bf2(f.v[4], f.v[5]),
+                            pack_bf2(f.v[6], f.v[7]));
+}
+__device__ __forceinline__ F8 ld_f8(const char* p) {
+    const float4 a = *(const float4*)p, b = *(const float4*)(p + 16);
+    F8 r;
+    r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = a.w;
+    r.v[4] = b.x; r.v[5] = b.y; r.v[6] = b.z; r.v[7] = b.w;
+    return r;
+}
+__device__ __forceinline__ void st_f8(char* p, const F8& f) {
+    *(float4*)p = make_float4(f.v[0], f.v[1], f.v[2], f.v[3]);
+    *(float4*)(p + 16) = make_float4(f.v[4], f.v[5], f.v[6], f.v[7]);
+}
+
+// A CB8 bf16 view: `p` already points at the first channel block of interest of image 0;
+// img = bytes between images.  p == nullptr means "absent" (treated as zeros).
+struct Cb8View {
+    const char* p;
+    long long img;
+};
+
+// ConvLSTM cell, pointwise backward of one timestep (all images of the step):
+//   dh = sum of up to three incoming hidden-state gradients, dc_in = gradient of c_t from step t+1
+//   tc = tanh(c_t);  do = dh*tc;  dct = dc_in + dh*o*(1-tc^2)
+//   dz = [dct*g*i(1-i), dct*c_prev*f(1-f), do*o(1-o), dct*i*(1-g^2)]   (gate-major, like `gates`)
+//   dc_prev = dct*f
+struct LstmBwdArgs {
+    int B, ncb, H, W;              // ncb = Ch / 8
+    Cb8View dh0, dh1, dh2;         // bf16 CB8 views of ncb blocks
+    const char* dc_in;             // fp32 CB8 [B][ncb] or null
+    const char* gates;             // bf16 CB8 [B][4*ncb]
+    const char* c_prev;            // fp32 CB8 [B][ncb]
+    const char* c_cur;             // fp32 CB8 [B][ncb]
+    char* dz;                      // bf16 CB8 [B][4*ncb]
+    char* dc_out;                  // fp32 CB8 [B][ncb]
+};
+
+__global__ void plc_lstm_pointwise_bwd_kernel(const LstmBwdArgs a) {
+    const long long hw = (long long)a.H * a.W;
+    const long long total = (long long)a.B * a.ncb * hw;
+    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const long long pix = idx % hw;
+        const int cb = (idx / hw) % a.ncb;
+        const long long b = idx / (hw * a.ncb);
+        const long long u = cb * hw + pix;        // unit inside an ncb-block image
+        F8 dh;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dh.v[j] = 0.0f;
+        const Cb8View views[3] = {a.dh0, a.dh1, a.dh2};
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            if (views[k].p) {
+                const F8 t = ld_bf8(views[k].p + b * views[k].img + u * 16);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) dh.v[j] += t.v[j];
+            }
+        const long long su = (b * a.ncb) * hw + u;              // unit index in [B][ncb] tensors
+        const long long gu = (b * 4 * a.ncb) * hw + u;          // unit index of gate 0 in [B][4 ncb]
+        F8 dcin;
+        if (a.dc_in) dcin = ld_f8(a.dc_in + su * 32);
+        else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) dcin.v[j] = 0.0f;
+        }
+        const F8 cp = ld_f8(a.c_prev + su * 32), cc = ld_f8(a.c_cur + su * 32);
+        const F8 gi = ld_bf8(a.gates + (gu + 0 * a.ncb * hw) * 16), gf = ld_bf8(a.gates + (gu + 1 * a.ncb * hw) * 16);
+        const F8 go = ld_bf8(a.gates + (gu + 2 * a.ncb * hw) * 16), gg = ld_bf8(a.gates + (gu + 3 * a.ncb * hw) * 16);
+        F8 zi, zf, zo, zg, dcp;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float tc = fast_tanh(cc.v[j]);
+            const float d_o = dh.v[j] * tc;
+            const float dct = dcin.v[j] + dh.v[j] * go.v[j] * (1.0f - tc * tc);
+            zi.v[j] = dct * gg.v[j] * gi.v[j] * (1.0f - gi.v[j]);
+            zf.v[j] = dct * cp.v[j] * gf.v[j] * (1.0f - gf.v[j]);
+            zo.v[j] = d_o * go.v[j] * (1.0f - go.v[j]);
+            zg.v[j] = dct * gi.v[j] * (1.0f - gg.v[j] * gg.v[j]);
+            dcp.v[j] = dct * gf.v[j];
+        }
+        st_bf8(a.dz + (gu + 0 * a.ncb * hw) * 16, zi);
+        st_bf8(a.dz + (gu + 1 * a.ncb * hw) * 16, zf);
+        st_bf8(a.dz + (gu + 2 * a.ncb * hw) * 16, zo);
+        st_bf8(a.dz + (gu + 3 * a.ncb * hw) * 16, zg);
+        st_f8(a.dc_out + su * 32, dcp);
+    }
+}
+
+// Gating backward, once per call, over (b, channel block, pixel); loops over the T frames:
+//   d_pre[t,b] = d_feat[t,b] * gate[b]                      (gradient of the un-gated feature map)
+//   dG[b]      = sum_t d_feat[t,b] * feat_pre[t,b]
+//   d_lu_pre[b]  = dG * gd * gl * (1 - gl)                  (through gate = gd * gl and the sigmoids)
+//   d_dem_pre[b] = dG * gl * gd * (1 - gd)
+// Images are enumerated t-major (n = t*B + b); every tensor is CB8 bf16 with ncb blocks.
+struct GateBwdArgs {
+    int B, T, ncb, H, W;
+    const char* d_feat;     // [T*B]
+    const char* feat_pre;   // [T*B]  feature map before gating
+    const char* gate;       // [B]    gd * gl
+    const char* gate_dem;   // [B]    gd
+    const char* gate_lu;    // [B]    gl
+    char* d_pre;            // [T*B]
+    char* d_lu_pre;         // [B]
+    char* d_dem_pre;        // [B]
+};
+
+__global__ void plc_gate_bwd_kernel(const GateBwdArgs a) {
+    const long long hw = (long long)a.H * a.W;
+    const long long img = (long long)a.ncb * hw;       // units per image
+    const long long total = (long long)a.B * img;
+    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const long long b = idx / img, u = idx % img;
+        const F8 g = ld_bf8(a.gate + idx * 16);
+        F8 acc;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc.v[j] = 0.0f;
+        for (int t = 0; t < a.T; ++t) {
+            const long long o = (((long long)t * a.B + b) * img + u) * 16;
+            const F8 df = ld_bf8(a.d_feat + o), fp = ld_bf8(a.feat_pre + o);
+            F8 dp;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                dp.v[j] = df.v[j] * g.v[j];
+                acc.v[j] += df.v[j] * fp.v[j];
+            }
+            st_bf8(a.d_pre + o, dp);
+        }
+        const F8 gd = ld_bf8(a.gate_dem + idx * 16), gl = ld_bf8(a.gate_lu + idx * 16);
+        F8 dl, dd;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            dl.v[j] = acc.v[j] * gd.v[j] * gl.v[j] * (1.0f - gl.v[j]);
+            dd.v[j] = acc.v[j] * gl.v[j] * gd.v[j] * (1.0f - gd.v[j]);
+        }
+        st_bf8(a.d_lu_pre + idx * 16, dl);
+        st_bf8(a.d_dem_pre + idx * 16, dd);
+    }
+}
+
+// out = mask > 0 ? d : 0 over N images of ncb blocks; d / mask / out are CB8 bf16 views.
+__global__ void plc_relu_mask_kernel(Cb8View d, Cb8View mask, char* out, long long out_img, int N, int ncb,
+                                     long long hw) {
+    const long long img = (long long)ncb * hw;
+    const long long total = (long long)N * img;
+    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const long long n = idx / img, u = idx % img;
+        const F8 g = ld_bf8(d.p + n * d.img + u * 16), m = ld_bf8(mask.p + n * mask.img + u * 16);
+        F8 r;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r.v[j] = m.v[j] > 0.0f ? g.v[j] : 0.0f;
+        st_bf8(out + n * out_img + u * 16, r);
+    }
+}
+
+// Backward of ReLU(PixelShuffle(2)(conv)):  d_conv[4c + 2i + j][y][x] = y_up[c][2y+i][2x+j] > 0 ?
+// d_up[c][2y+i][2x+j] : 0.   d_up / y_up: CB8 bf16 [N][C/8][2H][2W]; d_conv: CB8 bf16 [N][4C/8][H][W].
+__global__ void plc_pixel_unshuffle_mask_kernel(const char* __restrict__ d_up, const char* __restrict__ y_up,
+                                                char* __restrict__ d_conv, int N, int C, int H, int W) {
+    const long long hw = (long long)H * W;
+    const int ocb = 4 * C / 8;
+    const long long total = (long long)N * ocb * hw;
+    const long long W2 = 2 * W, hw2 = 4 * hw;
+    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const int x = idx % W;
+        const int y = (idx / W) % H;
+        const int cb = (idx / hw) % ocb;
+        const long long n = idx / (hw * ocb);
+        F8 r;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int o = 8 * cb + j;
+            const int c = o >> 2, sub = o & 3;
+            const long long pix2 = (long long)(2 * y + (sub >> 1)) * W2 + 2 * x + (sub & 1);
+            const long long e = (((n * (C / 8) + (c >> 3)) * hw2 + pix2) * 8 + (c & 7)) * 2;
+            const float dv = bf2f(*(const unsigned short*)(d_up + e));
+            const float yv = bf2f(*(const unsigned short*)(y_up + e));
+            r.v[j] = yv > 0.0f ? dv : 0.0f;
+        }
+        st_bf8(d_conv + idx * 16, r);
+    }
+}

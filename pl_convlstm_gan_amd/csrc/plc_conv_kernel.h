@@ -9,9 +9,13 @@
 //     [channel block][row][col] (8 channels of one pixel per unit), so the B fragment of a
 //     32-pixel row at any tap is one conflict-free ds_read_b128 per lane at an immediate offset;
 //   * the weights are stationary in registers: a wave holds the A fragments of ONE 32-row
-//     output tile for the whole K (NKS fragments of 16 bytes per lane), pre-packed by
+//     output tile for its share of K (16 bytes per lane per k-step), pre-packed by
 //     plc_pack_weight_kernel in exactly the lane order the MFMA wants, and sweeps the tile's
 //     pixel rows NREP at a time (NREP independent accumulators);
+//   * KSPLIT = 2 (used when K is too deep for one wave's registers, e.g. the data-gradient
+//     convs whose K is 4*Ch*9): two waves share an output tile, each contracts half of the
+//     input channel blocks, and the partial sums are exchanged through LDS once per pass so
+//     that each of the two waves finishes one of the pass's two pixel rows;
 //   * the row order inside a 32-row output tile is chosen per epilogue so that everything the
 //     epilogue combines sits in ONE lane: accumulator register 4g+j of lane (half, x) is row
 //     8g + 4*half + j, pixel x.  For the ConvLSTM cell g is the gate (i,f,o,g) and 4*half+j the
@@ -20,9 +24,10 @@
 #pragma once
 #include "plc_common.h"
 
-enum { STAGE_CB8 = 0, STAGE_CB8_GATED = 1, STAGE_COORD = 2 };
+enum { STAGE_CB8 = 0, STAGE_CB8_GATED = 1, STAGE_COORD = 2, STAGE_F32_1CH = 3 };
 enum { EPI_LSTM = 0, EPI_ACT_CB8 = 1, EPI_PIXSHUF_RELU = 2, EPI_F32_NCHW = 3 };
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_SIGMOID = 2 };
+enum { MUL_PRODUCT = 0, MUL_RELU_MASK = 1 };
 
 struct ConvArgs {
     int H, W;            // input == output spatial size (PixelShuffle epilogue writes 2H x 2W)
@@ -32,42 +37,174 @@ struct ConvArgs {
     int cout;            // EPI_F32_NCHW: number of fp32 channels stored
     int act;             // EPI_ACT_CB8 / EPI_F32_NCHW activation
     int save_gates;      // EPI_LSTM: also store i,f,o,g (bf16) for the backward pass
-    PlcTensor src0;      // CB8 bf16, first NCB0 channel blocks   (STAGE_COORD: fp32 plane)
+    int mul_mode;        // EPI_ACT_CB8 with `mul`: MUL_PRODUCT (v *= m) or MUL_RELU_MASK (v = m > 0 ? v : 0)
+    PlcTensor src0;      // CB8 bf16, first NCB0 channel blocks   (STAGE_COORD / STAGE_F32_1CH: fp32 plane)
     PlcTensor src1;      // CB8 bf16, next NCB1 channel blocks
     PlcTensor gate;      // STAGE_CB8_GATED: CB8 bf16 multiplier of src0
     const float* row_tab;  // STAGE_COORD: linspace(0,1,H)
     const float* col_tab;  // STAGE_COORD: linspace(0,1,W)
-    const uint4* wpk;    // packed A fragments [M tile][k step][lane] x 16 B
+    const uint4* wpk;    // packed A fragments [M tile][k split][k step][lane] x 16 B
     const float* bpk;    // packed bias [M tile][32 rows]
     PlcTensor c_in;      // EPI_LSTM: previous cell state, CB8 fp32
     PlcTensor out0;      // EPI_LSTM: h' (CB8 bf16); EPI_ACT_CB8/PIXSHUF: out (CB8 bf16); EPI_F32_NCHW: fp32
-    PlcTensor out1;      // EPI_LSTM: c' (CB8 fp32)
+    PlcTensor out1;      // EPI_LSTM: c' (CB8 fp32); EPI_ACT_CB8: optional copy of the value before `mul`
     PlcTensor out2;      // EPI_LSTM: gates i,f,o,g (CB8 bf16, 4*Ch channels) when save_gates
-    PlcTensor mul;       // EPI_ACT_CB8: optional CB8 bf16 tensor multiplied into the output (p may be null)
+    PlcTensor mul;       // EPI_ACT_CB8: optional CB8 bf16 tensor combined into the output (p may be null)
 };
 
-template <int NCB0, int NCB1, int NMT, int KS, int STAGE, int EPI, int TH>
+// One 16-byte LDS unit (8 channels of pixel (gy, gx) of channel block cb) of the conv input.
+template <int STAGE, int NCB0>
+__device__ __forceinline__ uint4 plc_stage_unit(const ConvArgs& a, const char* s0, const char* s1, const char* gt,
+                                                int cb, int gy, int gx, int H, int W) {
+    uint4 v = make_uint4(0, 0, 0, 0);
+    const bool ok = (gy >= 0) & (gy < H) & (gx >= 0) & (gx < W);
+    if (ok) {
+        const long long plane_b = (long long)H * W * 16;
+        const long long pix = ((long long)gy * W + gx) * 16;
+        if (STAGE == STAGE_COORD) {
+            const float rv = ((const float*)s0)[(long long)gy * W + gx];
+            v.x = pack_bf2(rv, a.row_tab[gy]);
+            v.y = pack_bf2(a.col_tab[gx], 0.0f);
+        } else if (STAGE == STAGE_F32_1CH) {
+            v.x = pack_bf2(((const float*)s0)[(long long)gy * W + gx], 0.0f);
+        } else if (STAGE == STAGE_CB8_GATED) {
+            const uint4 f = *(const uint4*)(s0 + cb * plane_b + pix);
+            const uint4 g = *(const uint4*)(gt + cb * plane_b + pix);
+            const float4 f0 = unpack_bf4(make_uint2(f.x, f.y)), f1 = unpack_bf4(make_uint2(f.z, f.w));
+            const float4 g0 = unpack_bf4(make_uint2(g.x, g.y)), g1 = unpack_bf4(make_uint2(g.z, g.w));
+            const uint2 lo = pack_bf4(f0.x * g0.x, f0.y * g0.y, f0.z * g0.z, f0.w * g0.w);
+            const uint2 hi = pack_bf4(f1.x * g1.x, f1.y * g1.y, f1.z * g1.z, f1.w * g1.w);
+            v = make_uint4(lo.x, lo.y, hi.x, hi.y);
+        } else {
+            const char* base = (cb < NCB0) ? (s0 + cb * plane_b) : (s1 + (cb - NCB0) * plane_b);
+            v = *(const uint4*)(base + pix);
+        }
+    }
+    return v;
+}
+
+// Epilogue of one pixel row of one 32-row output tile: acc register 4g+j = row 8g + 4*half + j.
+template <int EPI>
+__device__ __forceinline__ void plc_epilogue(const ConvArgs& a, const f32x16_t& acc, int n, int mt, int n_mt,
+                                             int gy, int gx, int half) {
+    const int H = a.H, W = a.W;
+    if (gy >= H || gx >= W) return;
+    const long long pix = (long long)gy * W + gx;
+    const long long plane_b = (long long)H * W * 16;
+    if (EPI == EPI_LSTM) {
+        const long long coff = ((long long)mt * H * W + pix) * 32 + half * 16;
+        const long long hoff = ((long long)mt * H * W + pix) * 16 + half * 8;
+        const float4 cp = *(const float4*)(plc_img(a.c_in, n, a.n_in) + coff);
+        float ig[4], fg[4], og[4], gg[4], cn[4], hn[4];
+        const float cpv[4] = {cp.x, cp.y, cp.z, cp.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            ig[j] = fast_sigmoid(acc[j]);
+            fg[j] = fast_sigmoid(acc[4 + j]);
+            og[j] = fast_sigmoid(acc[8 + j]);
+            gg[j] = fast_tanh(acc[12 + j]);
+            cn[j] = fg[j] * cpv[j] + ig[j] * gg[j];
+            hn[j] = og[j] * fast_tanh(cn[j]);
+        }
+        *(float4*)(plc_img(a.out1, n, a.n_in) + coff) = make_float4(cn[0], cn[1], cn[2], cn[3]);
+        *(uint2*)(plc_img(a.out0, n, a.n_in) + hoff) = pack_bf4(hn[0], hn[1], hn[2], hn[3]);
+        if (a.save_gates) {
+            // gates tensor: CB8 bf16 with 4*Ch channels in conv-output order (gate-major); n_mt = Ch / 8
+            char* gp = plc_img(a.out2, n, a.n_in) + pix * 16 + half * 8;
+            *(uint2*)(gp + (long long)(0 * n_mt + mt) * plane_b) = pack_bf4(ig[0], ig[1], ig[2], ig[3]);
+            *(uint2*)(gp + (long long)(1 * n_mt + mt) * plane_b) = pack_bf4(fg[0], fg[1], fg[2], fg[3]);
+            *(uint2*)(gp + (long long)(2 * n_mt + mt) * plane_b) = pack_bf4(og[0], og[1], og[2], og[3]);
+            *(uint2*)(gp + (long long)(3 * n_mt + mt) * plane_b) = pack_bf4(gg[0], gg[1], gg[2], gg[3]);
+        }
+    } else if (EPI == EPI_ACT_CB8) {
+        char* op = plc_img(a.out0, n, a.n_in);
+        char* op1 = a.out1.p ? plc_img(a.out1, n, a.n_in) : nullptr;
+        const char* mp = a.mul.p ? plc_img(a.mul, n, a.n_in) : nullptr;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int cb = 4 * mt + g;
+            if (cb >= a.ncb_out) continue;
+            float v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float t = acc[4 * g + j];
+                if (a.act == ACT_RELU) t = fmaxf(t, 0.0f);
+                else if (a.act == ACT_SIGMOID) t = fast_sigmoid(t);
+                v[j] = t;
+            }
+            const long long off = ((long long)cb * H * W + pix) * 16 + half * 8;
+            if (op1) *(uint2*)(op1 + off) = pack_bf4(v[0], v[1], v[2], v[3]);
+            if (mp) {
+                const float4 mv = unpack_bf4(*(const uint2*)(mp + off));
+                if (a.mul_mode == MUL_RELU_MASK) {
+                    v[0] = mv.x > 0.0f ? v[0] : 0.0f; v[1] = mv.y > 0.0f ? v[1] : 0.0f;
+                    v[2] = mv.z > 0.0f ? v[2] : 0.0f; v[3] = mv.w > 0.0f ? v[3] : 0.0f;
+                } else {
+                    v[0] *= mv.x; v[1] *= mv.y; v[2] *= mv.z; v[3] *= mv.w;
+                }
+            }
+            *(uint2*)(op + off) = pack_bf4(v[0], v[1], v[2], v[3]);
+        }
+    } else if (EPI == EPI_PIXSHUF_RELU) {
+        // row 8g + 4*half + j  <->  conv channel 4*(8*mt + 4*half + j) + g ; g = 2*i + jj
+        char* op = plc_img(a.out0, n, a.n_in);
+        const int H2 = 2 * H, W2 = 2 * W;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int oy = 2 * gy + (g >> 1), ox = 2 * gx + (g & 1);
+            const long long off = (((long long)mt * H2 + oy) * W2 + ox) * 16 + half * 8;
+            *(uint2*)(op + off) = pack_bf4(fmaxf(acc[4 * g + 0], 0.0f), fmaxf(acc[4 * g + 1], 0.0f),
+                                           fmaxf(acc[4 * g + 2], 0.0f), fmaxf(acc[4 * g + 3], 0.0f));
+        }
+    } else {  // EPI_F32_NCHW: channel = 32*mt + 8g + 4*half + j
+        float* op = (float*)plc_img(a.out0, n, a.n_in);
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int ch = 32 * mt + 8 * g + 4 * half + j;
+                if (ch >= a.cout) continue;
+                float t = acc[4 * g + j];
+                if (a.act == ACT_RELU) t = fmaxf(t, 0.0f);
+                else if (a.act == ACT_SIGMOID) t = fast_sigmoid(t);
+                op[(long long)ch * H * W + pix] = t;
+            }
+    }
+}
+
+// Dynamic LDS bytes of one instantiation.
+template <int NCB, int KS, int TH, int KSPLIT>
+constexpr int plc_conv_lds_bytes() {
+    return (NCB * (TH + 2 * (KS / 2)) * (32 + 2 * (KS / 2)) + (KSPLIT == 2 ? 4 * 4 * 64 : 0)) * 16;
+}
+
+template <int NCB0, int NCB1, int NMT, int KS, int STAGE, int EPI, int TH, int KSPLIT = 1>
 __global__ __launch_bounds__(256, 2) void plc_conv_mfma_kernel(const ConvArgs a) {
     constexpr int NCB = NCB0 + NCB1;
+    constexpr int NCBW = NCB / KSPLIT;       // channel blocks contracted by one wave
     constexpr int TAPS = KS * KS;
-    constexpr int UNITS = TAPS * NCB;
-    constexpr int NKS = (UNITS + 1) / 2;
+    constexpr int UNITS = TAPS * NCBW;
+    constexpr int NKS = (UNITS + 1) / 2;     // k-steps per wave
     constexpr int PAD = KS / 2;
     constexpr int LH = TH + 2 * PAD;
     constexpr int LW = 32 + 2 * PAD;
     constexpr int PLANE = LH * LW;           // units per channel block
-    constexpr int RG = 4 / NMT;              // row groups (waves sharing one M tile)
-    constexpr int RPW = TH / RG;             // rows per wave
+    constexpr int RG = 4 / (NMT * KSPLIT);   // row groups (wave sets sharing one M tile)
+    constexpr int RPW = TH / RG;             // rows per wave (per wave pair when KSPLIT == 2)
     // rows (N tiles) per pass: 4 accumulators, or 2 when the stationary weights already take
     // more than ~100 VGPRs (a single 32x32x16 accumulation chain issues back to back anyway)
-    constexpr int NREP_MAX = (NKS * 4 > 100) ? 2 : 4;
+    constexpr int NREP_MAX = (KSPLIT == 2 || NKS * 4 > 100) ? 2 : 4;
     constexpr int NREP = RPW < NREP_MAX ? RPW : NREP_MAX;
     constexpr int PASSES = RPW / NREP;
-    static_assert(NMT == 1 || NMT == 2 || NMT == 4, "NMT must be 1, 2 or 4");
+    static_assert(KSPLIT == 1 || KSPLIT == 2, "KSPLIT must be 1 or 2");
+    static_assert(NCB % KSPLIT == 0, "channel blocks must split evenly");
+    static_assert(NMT * KSPLIT == 1 || NMT * KSPLIT == 2 || NMT * KSPLIT == 4, "NMT*KSPLIT must be 1, 2 or 4");
     static_assert(RPW >= 1 && RPW % NREP == 0, "tile rows must split evenly over waves");
-    static_assert(NCB * PLANE * 16 <= 65536, "LDS tile too large");
+    static_assert(KSPLIT == 1 || NREP == 2, "K split needs two rows per pass");
+    constexpr int RED_UNITS = KSPLIT == 2 ? 4 * 4 * 64 : 0;   // partial-sum exchange, 16 B units
+    static_assert((NCB * PLANE + RED_UNITS) * 16 <= 160 * 1024, "LDS tile too large");
 
-    __shared__ __attribute__((aligned(16))) uint4 tile[NCB * PLANE];
+    extern __shared__ __attribute__((aligned(16))) uint4 tile[];   // (NCB * PLANE + RED_UNITS) units
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -75,8 +212,10 @@ __global__ __launch_bounds__(256, 2) void plc_conv_mfma_kernel(const ConvArgs a)
     const int half = lane >> 5;
     const int px = lane & 31;
     const int m = wave % NMT;
-    const int rg = wave / NMT;
+    const int ks = (wave / NMT) % KSPLIT;
+    const int rg = wave / (NMT * KSPLIT);
     const int mt = blockIdx.y * NMT + m;     // global M tile index
+    const int n_mt = gridDim.y * NMT;
 
     int bid = blockIdx.x;
     const int tx = bid % a.tiles_x;
@@ -85,12 +224,11 @@ __global__ __launch_bounds__(256, 2) void plc_conv_mfma_kernel(const ConvArgs a)
     const int n = bid / a.tiles_y;
     const int x0 = tx * 32, y0 = ty * TH;
     const int H = a.H, W = a.W;
-    const long long plane_b = (long long)H * W * 16;  // bytes per bf16 channel block plane
 
     // ---- weights: stationary A fragments -------------------------------------------------
     bf16x8_t wf[NKS];
     {
-        const uint4* wp = a.wpk + ((long long)mt * NKS) * 64 + lane;
+        const uint4* wp = a.wpk + ((long long)(mt * KSPLIT + ks) * NKS) * 64 + lane;
 #pragma unroll
         for (int s = 0; s < NKS; ++s) wf[s] = __builtin_bit_cast(bf16x8_t, wp[s * 64]);
     }
@@ -105,29 +243,7 @@ __global__ __launch_bounds__(256, 2) void plc_conv_mfma_kernel(const ConvArgs a)
             const int r = u - cb * PLANE;
             const int ly = r / LW;
             const int lx = r - ly * LW;
-            const int gy = y0 - PAD + ly, gx = x0 - PAD + lx;
-            const bool ok = (gy >= 0) & (gy < H) & (gx >= 0) & (gx < W);
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (ok) {
-                const long long pix = ((long long)gy * W + gx) * 16;
-                if (STAGE == STAGE_COORD) {
-                    const float rv = ((const float*)s0)[(long long)gy * W + gx];
-                    v.x = pack_bf2(rv, a.row_tab[gy]);
-                    v.y = pack_bf2(a.col_tab[gx], 0.0f);
-                } else if (STAGE == STAGE_CB8_GATED) {
-                    const uint4 f = *(const uint4*)(s0 + cb * plane_b + pix);
-                    const uint4 g = *(const uint4*)(gt + cb * plane_b + pix);
-                    const float4 f0 = unpack_bf4(make_uint2(f.x, f.y)), f1 = unpack_bf4(make_uint2(f.z, f.w));
-                    const float4 g0 = unpack_bf4(make_uint2(g.x, g.y)), g1 = unpack_bf4(make_uint2(g.z, g.w));
-                    const uint2 lo = pack_bf4(f0.x * g0.x, f0.y * g0.y, f0.z * g0.z, f0.w * g0.w);
-                    const uint2 hi = pack_bf4(f1.x * g1.x, f1.y * g1.y, f1.z * g1.z, f1.w * g1.w);
-                    v = make_uint4(lo.x, lo.y, hi.x, hi.y);
-                } else {
-                    const char* base = (cb < NCB0) ? (s0 + cb * plane_b) : (s1 + (cb - NCB0) * plane_b);
-                    v = *(const uint4*)(base + pix);
-                }
-            }
-            tile[u] = v;
+            tile[u] = plc_stage_unit<STAGE, NCB0>(a, s0, s1, gt, cb, y0 - PAD + ly, x0 - PAD + lx, H, W);
         }
     }
     __syncthreads();
@@ -142,7 +258,10 @@ __global__ __launch_bounds__(256, 2) void plc_conv_mfma_kernel(const ConvArgs a)
         {
             float4 bv[4];
 #pragma unroll
-            for (int g = 0; g < 4; ++g) bv[g] = bias4[2 * g + half];
+            for (int g = 0; g < 4; ++g) {
+                bv[g] = bias4[2 * g + half];
+                if (KSPLIT == 2 && ks != 0) bv[g] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
 #pragma unroll
             for (int r = 0; r < NREP; ++r)
 #pragma unroll
@@ -153,111 +272,69 @@ __global__ __launch_bounds__(256, 2) void plc_conv_mfma_kernel(const ConvArgs a)
                     acc[r][4 * g + 3] = bv[g].w;
                 }
         }
-        // per-lane LDS byte address of this pass's first row at tap (0,0), channel block 0
+        // per-lane LDS byte address of this pass's first row at tap (0,0), first channel block of this wave
         int abase[NREP];
 #pragma unroll
         for (int r = 0; r < NREP; ++r) {
-            abase[r] = ((row0 + r) * LW + px) * 16;
-            if (NCB % 2 == 0) abase[r] += half * PLANE * 16;
+            abase[r] = ((row0 + r) * LW + px) * 16 + ks * NCBW * PLANE * 16;
+            if (NCBW % 2 == 0) abase[r] += half * PLANE * 16;
         }
 #pragma unroll
         for (int s = 0; s < NKS; ++s) {
-            // unit u = tap * NCB + cb; lanes 0-31 take unit 2s, lanes 32-63 unit 2s+1
+            // unit u = tap * NCBW + cb; lanes 0-31 take unit 2s, lanes 32-63 unit 2s+1
             const int u0 = 2 * s, u1 = 2 * s + 1;
-            const int t0 = u0 / NCB, c0 = u0 % NCB;
-            const int t1 = (u1 < UNITS) ? u1 / NCB : 0, c1 = (u1 < UNITS) ? u1 % NCB : 0;
+            const int t0 = u0 / NCBW, c0 = u0 % NCBW;
+            const int t1 = (u1 < UNITS) ? u1 / NCBW : 0, c1 = (u1 < UNITS) ? u1 % NCBW : 0;
             const int off0 = (c0 * PLANE + (t0 / KS) * LW + (t0 % KS)) * 16;
             const int off1 = (c1 * PLANE + (t1 / KS) * LW + (t1 % KS)) * 16;
 #pragma unroll
             for (int r = 0; r < NREP; ++r) {
                 int addr;
-                if (NCB % 2 == 0) addr = abase[r] + off0;          // off1 == off0 + PLANE*16 folded in abase
+                if (NCBW % 2 == 0) addr = abase[r] + off0;         // off1 == off0 + PLANE*16 folded in abase
                 else addr = abase[r] + (half ? off1 : off0);
                 const bf16x8_t bfrag = *(const bf16x8_t*)(lds + addr);
                 acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s], bfrag, acc[r], 0, 0, 0);
             }
         }
 
-        // ---- epilogue ----------------------------------------------------------------------
-#pragma unroll
-        for (int r = 0; r < NREP; ++r) {
-            const int gy = y0 + row0 + r, gx = x0 + px;
-            if (gy >= H || gx >= W) continue;
-            const long long pix = (long long)gy * W + gx;
-            if (EPI == EPI_LSTM) {
-                const long long coff = ((long long)mt * H * W + pix) * 32 + half * 16;
-                const long long hoff = ((long long)mt * H * W + pix) * 16 + half * 8;
-                const float4 cp = *(const float4*)(plc_img(a.c_in, n, a.n_in) + coff);
-                float ig[4], fg[4], og[4], gg[4], cn[4], hn[4];
-                const float cpv[4] = {cp.x, cp.y, cp.z, cp.w};
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    ig[j] = fast_sigmoid(acc[r][j]);
-                    fg[j] = fast_sigmoid(acc[r][4 + j]);
-                    og[j] = fast_sigmoid(acc[r][8 + j]);
-                    gg[j] = fast_tanh(acc[r][12 + j]);
-                    cn[j] = fg[j] * cpv[j] + ig[j] * gg[j];
-                    hn[j] = og[j] * fast_tanh(cn[j]);
-                }
-                *(float4*)(plc_img(a.out1, n, a.n_in) + coff) = make_float4(cn[0], cn[1], cn[2], cn[3]);
-                *(uint2*)(plc_img(a.out0, n, a.n_in) + hoff) = pack_bf4(hn[0], hn[1], hn[2], hn[3]);
-                if (a.save_gates) {
-                    // gates tensor: CB8 bf16 with 4*Ch channels in conv-output order (gate-major)
-                    const int cbs = gridDim.y * NMT;  // channel blocks per gate = Ch / 8
-                    char* gp = plc_img(a.out2, n, a.n_in) + pix * 16 + half * 8;
-                    *(uint2*)(gp + (long long)(0 * cbs + mt) * plane_b) = pack_bf4(ig[0], ig[1], ig[2], ig[3]);
-                    *(uint2*)(gp + (long long)(1 * cbs + mt) * plane_b) = pack_bf4(fg[0], fg[1], fg[2], fg[3]);
-                    *(uint2*)(gp + (long long)(2 * cbs + mt) * plane_b) = pack_bf4(og[0], og[1], og[2], og[3]);
-                    *(uint2*)(gp + (long long)(3 * cbs + mt) * plane_b) = pack_bf4(gg[0], gg[1], gg[2], gg[3]);
-                }
-            } else if (EPI == EPI_ACT_CB8) {
-                char* op = plc_img(a.out0, n, a.n_in);
-                const char* mp = a.mul.p ? plc_img(a.mul, n, a.n_in) : nullptr;
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int cb = 4 * mt + g;
-                    if (cb >= a.ncb_out) continue;
-                    float v[4];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        float t = acc[r][4 * g + j];
-                        if (a.act == ACT_RELU) t = fmaxf(t, 0.0f);
-                        else if (a.act == ACT_SIGMOID) t = fast_sigmoid(t);
-                        v[j] = t;
-                    }
-                    const long long off = ((long long)cb * H * W + pix) * 16 + half * 8;
-                    if (mp) {
-                        const float4 mv = unpack_bf4(*(const uint2*)(mp + off));
-                        v[0] *= mv.x; v[1] *= mv.y; v[2] *= mv.z; v[3] *= mv.w;
-                    }
-                    *(uint2*)(op + off) = pack_bf4(v[0], v[1], v[2], v[3]);
-                }
-            } else if (EPI == EPI_PIXSHUF_RELU) {
-                // row 8g + 4*half + j  <->  conv channel 4*(8*mt + 4*half + j) + g ; g = 2*i + jj
-                char* op = plc_img(a.out0, n, a.n_in);
-                const int H2 = 2 * H, W2 = 2 * W;
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int oy = 2 * gy + (g >> 1), ox = 2 * gx + (g & 1);
-                    const long long off = (((long long)mt * H2 + oy) * W2 + ox) * 16 + half * 8;
-                    *(uint2*)(op + off) = pack_bf4(fmaxf(acc[r][4 * g + 0], 0.0f), fmaxf(acc[r][4 * g + 1], 0.0f),
-                                                   fmaxf(acc[r][4 * g + 2], 0.0f), fmaxf(acc[r][4 * g + 3], 0.0f));
-                }
-            } else {  // EPI_F32_NCHW: channel = 32*mt + 8g + 4*half + j
-                float* op = (float*)plc_img(a.out0, n, a.n_in);
+        if constexpr (KSPLIT == 2) {
+            // exchange partial sums: wave ks finishes row ks of the pass, its partner the other row
+            float4* red = (float4*)(tile + NCB * PLANE);
+            float4* mine = red + wave * 256 + lane;
+            const float4* theirs = red + (wave ^ NMT) * 256 + lane;
+            if (ks == 0) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
+                    mine[g * 64] = make_float4(acc[1][4 * g], acc[1][4 * g + 1], acc[1][4 * g + 2], acc[1][4 * g + 3]);
+            } else {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int ch = 32 * mt + 8 * g + 4 * half + j;
-                        if (ch >= a.cout) continue;
-                        float t = acc[r][4 * g + j];
-                        if (a.act == ACT_RELU) t = fmaxf(t, 0.0f);
-                        else if (a.act == ACT_SIGMOID) t = fast_sigmoid(t);
-                        op[(long long)ch * H * W + pix] = t;
-                    }
+                for (int g = 0; g < 4; ++g)
+                    mine[g * 64] = make_float4(acc[0][4 * g], acc[0][4 * g + 1], acc[0][4 * g + 2], acc[0][4 * g + 3]);
             }
-            __builtin_amdgcn_sched_barrier(0);  // keep the NREP epilogues from interleaving (register pressure)
+            __syncthreads();
+            if (ks == 0) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float4 t = theirs[g * 64];
+                    acc[0][4 * g] += t.x; acc[0][4 * g + 1] += t.y; acc[0][4 * g + 2] += t.z; acc[0][4 * g + 3] += t.w;
+                }
+                plc_epilogue<EPI>(a, acc[0], n, mt, n_mt, y0 + row0, x0 + px, half);
+            } else {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float4 t = theirs[g * 64];
+                    acc[NREP - 1][4 * g] += t.x; acc[NREP - 1][4 * g + 1] += t.y;
+                    acc[NREP - 1][4 * g + 2] += t.z; acc[NREP - 1][4 * g + 3] += t.w;
+                }
+                plc_epilogue<EPI>(a, acc[NREP - 1], n, mt, n_mt, y0 + row0 + 1, x0 + px, half);
+            }
+            __syncthreads();   // the exchange buffer is reused by the next pass
+        } else {
+#pragma unroll
+            for (int r = 0; r < NREP; ++r) {
+                plc_epilogue<EPI>(a, acc[r], n, mt, n_mt, y0 + row0 + r, x0 + px, half);
+                __builtin_amdgcn_sched_barrier(0);  // keep the NREP epilogues from interleaving (register pressure)
+            }
         }
     }
 }

@@ -12,44 +12,68 @@ __device__ __forceinline__ int plc_row_to_cout(int mode, int mt, int r, int ch_p
     return 32 * mt + r;
 }
 
+// Map a channel index of the block-padded concat [src0 blocks | src1 blocks] to the index in the
+// unpadded concat [c0 | c1], or -1 for a padding channel.
+__device__ __forceinline__ int plc_padded_to_concat(int cb, int j, int c0, int c1) {
+    const int ncb0 = (c0 + 7) / 8;
+    if (cb < ncb0) return (8 * cb + j < c0) ? 8 * cb + j : -1;
+    return (8 * (cb - ncb0) + j < c1) ? c0 + 8 * (cb - ncb0) + j : -1;
+}
+
 // w: fp32 [cout][c0 + c1][ks][ks] (cross-correlation weights, PyTorch layout)
-// wpk: bf16 [n_mt][nks][64 lanes][8], lane l = (half, row): k index 16 s + 8 half + j is
-//      unit u = 2s + half = tap * ncb + cb, channel 8 cb + j of the block-padded concat [src0 | src1].
-// transposed != 0 packs the data-gradient weights instead: W'[ci][co][ks-1-dy][ks-1-dx] viewed
-//      as a conv from cout (w's dim 0, in blocks of c0=cout) to cin channels.
+// wpk: bf16 [n_mt][ksplit][nks_w][64 lanes][8].  Lane l = (half, row) of k-split part q holds
+//      k index 16 s + 8 half + j = unit u = 2s + half = tap * ncbw + cb' of channel block
+//      cb = q * ncbw + cb', channel 8 cb + j.
+// transposed == 0 (forward conv):  rows = output channels (regrouped per `mode`), K channels = the
+//      block-padded concat [src0 | src1];
+// transposed != 0 (data gradient): rows = channels of the block-padded concat [src0 | src1]
+//      (plain order), K channels = the cout output channels, taps flipped:
+//      W'[ci][o][dy][dx] = w[o][ci][ks-1-dy][ks-1-dx].
 __global__ void plc_pack_weight_kernel(const float* __restrict__ w, const float* __restrict__ bias,
                                        unsigned short* __restrict__ wpk, float* __restrict__ bpk,
-                                       int cout, int c0, int c1, int ks, int mode, int n_mt, int nks,
-                                       int ch_per_gate) {
-    const int ncb0 = (c0 + 7) / 8, ncb1 = (c1 + 7) / 8, ncb = ncb0 + ncb1;
+                                       int cout, int c0, int c1, int ks, int mode, int n_mt, int nks_w,
+                                       int ch_per_gate, int transposed, int ksplit) {
+    const int ncb_k = transposed ? (cout + 7) / 8 : (c0 + 7) / 8 + (c1 + 7) / 8;
+    const int ncbw = ncb_k / ksplit;
     const int taps = ks * ks;
-    const long long total = (long long)n_mt * nks * 64 * 8;
+    const long long total = (long long)n_mt * ksplit * nks_w * 64 * 8;
     for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
          idx += (long long)gridDim.x * blockDim.x) {
         const int j = idx & 7;
         const int lane = (idx >> 3) & 63;
-        const int s = (idx >> 9) % nks;
-        const int mt = (idx >> 9) / nks;
+        long long rest = idx >> 9;
+        const int s = rest % nks_w;
+        rest /= nks_w;
+        const int q = rest % ksplit;
+        const int mt = rest / ksplit;
         const int r = lane & 31, half = lane >> 5;
         const int u = 2 * s + half;
-        const int tap = u / ncb, cb = u % ncb;
+        const int tap = u / ncbw, cb = q * ncbw + u % ncbw;
         float v = 0.0f;
-        const int o = plc_row_to_cout(mode, mt, r, ch_per_gate);
-        if (tap < taps && o < cout) {
-            int ci = -1;
-            if (cb < ncb0) {
-                if (8 * cb + j < c0) ci = 8 * cb + j;
+        if (tap < taps) {
+            const int dy = tap / ks, dx = tap % ks;
+            if (!transposed) {
+                const int o = plc_row_to_cout(mode, mt, r, ch_per_gate);
+                const int ci = plc_padded_to_concat(cb, j, c0, c1);
+                if (o < cout && ci >= 0) v = w[(((long long)o * (c0 + c1) + ci) * ks + dy) * ks + dx];
             } else {
-                if (8 * (cb - ncb0) + j < c1) ci = c0 + 8 * (cb - ncb0) + j;
+                const int rowg = 32 * mt + r;
+                const int ci = plc_padded_to_concat(rowg >> 3, rowg & 7, c0, c1);
+                const int o = 8 * cb + j;
+                if (o < cout && ci >= 0 && (rowg >> 3) < (c0 + 7) / 8 + (c1 + 7) / 8)
+                    v = w[(((long long)o * (c0 + c1) + ci) * ks + (ks - 1 - dy)) * ks + (ks - 1 - dx)];
             }
-            if (ci >= 0) v = w[(((long long)o * (c0 + c1) + ci) * ks + tap / ks) * ks + tap % ks];
         }
         wpk[idx] = f2bf(v);
     }
     if (bpk) {
         for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_mt * 32; i += gridDim.x * blockDim.x) {
-            const int o = plc_row_to_cout(mode, i >> 5, i & 31, ch_per_gate);
-            bpk[i] = (bias && o < cout) ? bias[o] : 0.0f;
+            float b = 0.0f;
+            if (!transposed && bias) {
+                const int o = plc_row_to_cout(mode, i >> 5, i & 31, ch_per_gate);
+                if (o < cout) b = bias[o];
+            }
+            bpk[i] = b;
         }
     }
 }

@@ -1,0 +1,236 @@
+// Weight gradient of a KSxKS conv on gfx950 matrix cores.
+//
+//   dW[o][ci][tap] = sum over images and pixels of  dz[o][p] * in[ci][p + tap],   db[o] = sum dz[o][p]
+//
+// GEMM view: D[row = output channel o][col = (tap, input channel)] with the contraction over
+// PIXELS.  The activations live in the CB8 layout (8 channels of one pixel per 16-byte unit),
+// i.e. the contraction index is the strided one, so both MFMA operands are fetched from LDS with
+// ds_read_b64_tr_b16 (the transposing LDS read): a 16-lane group reads a 4-pixel x 16-channel
+// block and every lane receives 4 consecutive pixels of its own channel.
+//
+//   * one persistent workgroup of 8 waves per CU walks 4 x 32 pixel tiles; each tile's dz block
+//     and (4+2) x 34 input halo block are double-buffered in LDS (next tile's global loads are in
+//     flight while the current tile is contracted);
+//   * the whole dW of the conv stays in registers for the kernel's lifetime: wave (m, g) owns the
+//     32-row output tile m and NT_W 32-column tiles (f32x16 accumulators);
+//   * a column group is 16 input channels at one tap; one extra group whose B operand is the
+//     constant 1.0 yields the bias gradient from the same MFMAs;
+//   * every workgroup writes its partial dW to its own slab; plc_wgrad_finalize_kernel sums the
+//     slabs in a fixed order (bitwise reproducible, no atomics) and scatters into the PyTorch
+//     weight layout.
+#pragma once
+#include "plc_conv_kernel.h"
+#include "plc_misc_kernels.h"
+
+typedef __attribute__((__vector_size__(4 * sizeof(short)))) short s16x4_t;
+#define PLC_AS3 __attribute__((address_space(3)))
+
+struct WgradArgs {
+    ConvArgs in;       // H, W, tiles_x, tiles_y, n_in and the staging fields (src0, src1, gate, tabs)
+    PlcTensor dz;      // CB8 bf16, ceil(cout/8) channel blocks
+    int mcb_valid;     // channel blocks present in dz
+    int n_tiles;       // n_img * tiles_y * tiles_x
+    float* slab;       // [gridDim.x][MT*32][NT*32]
+};
+
+constexpr int WG_TH = 4;
+
+template <int NCB, int MT, int KS>
+struct WgradGeom {
+    static constexpr int TAPS = KS * KS;
+    static constexpr int PAD = KS / 2;
+    static constexpr int LH = WG_TH + 2 * PAD;
+    static constexpr int LW = 32 + 2 * PAD;
+    static constexpr int PLANE = LH * LW;
+    static constexpr int MCB = 4 * MT;
+    static constexpr int NCBP = (NCB + 1) / 2;
+    static constexpr int NG = TAPS * NCBP + 1;          // + bias group
+    static constexpr int NT = (NG + 1) / 2;
+    static constexpr int WN = 8 / MT;                   // N groups of waves
+    static constexpr int NT_W = (NT + WN - 1) / WN;
+    static constexpr int IN_UNITS = NCB * PLANE;
+    static constexpr int DZ_UNITS = MCB * WG_TH * 32;
+    static constexpr int CONST_UNITS = 128;             // 2 KiB: covers every k-step offset of a tile
+    static constexpr int BUF_UNITS = IN_UNITS + DZ_UNITS + 2 * CONST_UNITS;   // [in | dz | zeros | ones]
+    static constexpr int LDS_BYTES = 2 * BUF_UNITS * 16;
+    static constexpr int NPF = (IN_UNITS + DZ_UNITS + 511) / 512;
+};
+
+template <int NCB0, int NCB1, int MT, int KS, int STAGE>
+__global__ __launch_bounds__(512, 2) void plc_wgrad_kernel(const WgradArgs a) {
+    using G = WgradGeom<NCB0 + NCB1, MT, KS>;
+    constexpr int NCB = NCB0 + NCB1;
+    static_assert(MT == 1 || MT == 2 || MT == 4, "MT must be 1, 2 or 4");
+    static_assert(((WG_TH - 1) * G::LW + 16) * 16 + 80 <= G::CONST_UNITS * 16, "constant region too small");
+    extern __shared__ __attribute__((aligned(16))) uint4 smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int m = wave % MT;
+    const int ng = wave / MT;
+    const int g16 = lane >> 4;          // 16-lane group: channels 16*(g16&1).., pixel half g16>>1
+    const int khalf = g16 >> 1;
+    const int li = lane & 15;
+    const int q = li >> 2, p = li & 3;  // lane supplies pixel q, channels 4p..4p+3 of the group's 16
+    const int H = a.in.H, W = a.in.W;
+
+    // constant regions of both buffers
+    for (int i = tid; i < 2 * 2 * G::CONST_UNITS; i += 512) {
+        const int buf = i / (2 * G::CONST_UNITS), r = i % (2 * G::CONST_UNITS);
+        const unsigned v = r < G::CONST_UNITS ? 0u : 0x3F803F80u;
+        smem[buf * G::BUF_UNITS + G::IN_UNITS + G::DZ_UNITS + r] = make_uint4(v, v, v, v);
+    }
+
+    // per-lane byte addresses (buffer 0, k-step 0) of the two transposed reads of each fragment
+    const int pix_off = (8 * khalf + q) * 16 + (p & 1) * 8;
+    int a_addr;   // A: dz block, channel block 4m + 2*(g16&1) + (p>>1)
+    {
+        const int cb = 4 * m + 2 * (g16 & 1) + (p >> 1);
+        a_addr = (G::IN_UNITS + cb * WG_TH * 32) * 16 + pix_off;
+    }
+    int b_addr[G::NT_W];
+#pragma unroll
+    for (int i = 0; i < G::NT_W; ++i) {
+        const int nt = ng * G::NT_W + i;
+        const int grp = 2 * nt + (g16 & 1);
+        int addr;
+        if (grp < G::TAPS * G::NCBP) {
+            const int tap = grp / G::NCBP, cbp = grp % G::NCBP;
+            const int cb = 2 * cbp + (p >> 1);
+            if (cb < NCB) addr = ((cb * G::LH + tap / KS) * G::LW + tap % KS) * 16 + pix_off;
+            else addr = (G::IN_UNITS + G::DZ_UNITS) * 16 + (p & 1) * 8;                         // zeros
+        } else if (grp == G::TAPS * G::NCBP) {
+            addr = (G::IN_UNITS + G::DZ_UNITS + G::CONST_UNITS) * 16 + (p & 1) * 8;             // ones (bias)
+        } else {
+            addr = (G::IN_UNITS + G::DZ_UNITS) * 16 + (p & 1) * 8;                              // zeros
+        }
+        b_addr[i] = addr;
+    }
+
+    f32x16_t acc[G::NT_W];
+#pragma unroll
+    for (int i = 0; i < G::NT_W; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+
+    const int tiles_per_img = a.in.tiles_x * a.in.tiles_y;
+
+    // ---- tile loader: global -> registers, registers -> LDS ---------------------------------
+    uint4 pf[G::NPF];
+    auto load_tile = [&](int t) {
+        const int n = t / tiles_per_img;
+        const int rem = t - n * tiles_per_img;
+        const int ty = rem / a.in.tiles_x, tx = rem - ty * a.in.tiles_x;
+        const int x0 = tx * 32, y0 = ty * WG_TH;
+        const char* s0 = plc_img(a.in.src0, n, a.in.n_in);
+        const char* s1 = NCB1 > 0 ? plc_img(a.in.src1, n, a.in.n_in) : nullptr;
+        const char* gt = STAGE == STAGE_CB8_GATED ? plc_img(a.in.gate, n, a.in.n_in) : nullptr;
+        const char* dzp = plc_img(a.dz, n, a.in.n_in);
+#pragma unroll
+        for (int k = 0; k < G::NPF; ++k) {
+            const int u = tid + k * 512;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (u < G::IN_UNITS) {
+                const int cb = u / G::PLANE;
+                const int r = u - cb * G::PLANE;
+                const int ly = r / G::LW, lx = r - ly * G::LW;
+                v = plc_stage_unit<STAGE, NCB0>(a.in, s0, s1, gt, cb, y0 - G::PAD + ly, x0 - G::PAD + lx, H, W);
+            } else if (u < G::IN_UNITS + G::DZ_UNITS) {
+                const int d = u - G::IN_UNITS;
+                const int cb = d / (WG_TH * 32);
+                const int r = d - cb * (WG_TH * 32);
+                const int gy = y0 + (r >> 5), gx = x0 + (r & 31);
+                if (cb < a.mcb_valid && gy < H && gx < W)
+                    v = *(const uint4*)(dzp + (((long long)cb * H + gy) * W + gx) * 16);
+            }
+            pf[k] = v;
+        }
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int k = 0; k < G::NPF; ++k) {
+            const int u = tid + k * 512;
+            if (u < G::IN_UNITS + G::DZ_UNITS) smem[buf * G::BUF_UNITS + u] = pf[k];
+        }
+    };
+
+    int t = blockIdx.x;
+    int buf = 0;
+    if (t < a.n_tiles) {
+        load_tile(t);
+        store_tile(0);
+    }
+    __syncthreads();
+    PLC_AS3 char* lds = (PLC_AS3 char*)smem;
+
+    for (; t < a.n_tiles; t += gridDim.x) {
+        const int tn = t + gridDim.x;
+        if (tn < a.n_tiles) load_tile(tn);            // next tile's loads fly during the MFMAs below
+        const int boff = buf * G::BUF_UNITS * 16;
+#pragma unroll
+        for (int ks = 0; ks < WG_TH * 2; ++ks) {
+            const int row = ks >> 1, xk = (ks & 1) * 16;
+            const int offa = (row * 32 + xk) * 16;
+            const int offb = (row * G::LW + xk) * 16;
+            const s16x4_t a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((PLC_AS3 s16x4_t*)(lds + boff + a_addr + offa));
+            const s16x4_t a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((PLC_AS3 s16x4_t*)(lds + boff + a_addr + offa + 64));
+            const bf16x8_t af = __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7));
+#pragma unroll
+            for (int i = 0; i < G::NT_W; ++i) {
+                const s16x4_t b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((PLC_AS3 s16x4_t*)(lds + boff + b_addr[i] + offb));
+                const s16x4_t b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((PLC_AS3 s16x4_t*)(lds + boff + b_addr[i] + offb + 64));
+                const bf16x8_t bfr = __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7));
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, acc[i], 0, 0, 0);
+            }
+        }
+        if (tn < a.n_tiles) store_tile(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+    }
+
+    // ---- partial dW of this workgroup -> its slab ---------------------------------------------
+    float* slab = a.slab + (long long)blockIdx.x * (MT * 32) * (G::NT * 32);
+    const int half = lane >> 5, col = lane & 31;
+#pragma unroll
+    for (int i = 0; i < G::NT_W; ++i) {
+        const int nt = ng * G::NT_W + i;
+        if (nt >= G::NT) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+            slab[(long long)(32 * m + row) * (G::NT * 32) + nt * 32 + col] = acc[i][r];
+        }
+    }
+}
+
+// Sum the per-workgroup slabs (fixed order) and scatter into dW [cout][c0+c1][ks][ks], db [cout].
+__global__ void plc_wgrad_finalize_kernel(const float* __restrict__ slab, int n_slabs, int rows_pad, int cols_pad,
+                                          float* __restrict__ dw, float* __restrict__ db, int cout, int c0, int c1,
+                                          int ks, int ncb) {
+    const int taps = ks * ks, ncbp = (ncb + 1) / 2;
+    const long long total = (long long)cout * cols_pad;
+    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const int o = idx / cols_pad, ncol = idx % cols_pad;
+        const int grp = ncol >> 4, c16 = ncol & 15;
+        int ci = -1, tap = 0;
+        bool is_bias = false;
+        if (grp < taps * ncbp) {
+            tap = grp / ncbp;
+            const int cb = 2 * (grp % ncbp) + (c16 >> 3);
+            if (cb < ncb) ci = plc_padded_to_concat(cb, c16 & 7, c0, c1);
+        } else if (grp == taps * ncbp && c16 == 0) {
+            is_bias = true;
+        }
+        if (ci < 0 && !is_bias) continue;
+        float s = 0.0f;
+        const float* p = slab + (long long)o * cols_pad + ncol;
+        for (int b = 0; b < n_slabs; ++b) s += p[(long long)b * rows_pad * cols_pad];
+        if (is_bias) {
+            if (db) db[o] = s;
+        } else {
+            dw[((long long)o * (c0 + c1) + ci) * taps + tap] = s;
+        }
+    }
+}

@@ -39,6 +39,9 @@ class ConvLSTMCell(nn.Module):
     def forward(self, x, h_cur, c_cur):
         if self.conv.kernel_size != (3, 3):
             raise NotImplementedError("only kernel_size=3 is compiled")
+        if torch.is_grad_enabled() and any(t.requires_grad for t in (x, h_cur, c_cur, self.conv.weight)):
+            from .autograd import cell_with_grad
+            return cell_with_grad(x, h_cur, c_cur, self.conv.weight, self.conv.bias)
         return ops.convlstm_cell_forward(x, h_cur, c_cur, self.conv.weight.detach(),
                                          None if self.conv.bias is None else self.conv.bias.detach())
 
@@ -223,19 +226,34 @@ class Generator(nn.Module):
         d.post2_w, d.post2_b = P(self.post_process[2].weight), P(self.post_process[2].bias)
         d.out = out.data_ptr()
 
-    def _workspace(self, d, device):
+    def _workspace(self, d, device, fresh=False):
         L = _lib.lib()
         nbytes = L.plc_generator_workspace_bytes(C.byref(d))
         if nbytes == 0:
             _lib.check(-2 if "compiled kernel set" in L.plc_last_error().decode() else -1, "Generator.forward")
-        key = (str(device), nbytes)
-        ws = self._ws.get(key)
-        if ws is None:
-            self._ws.clear()
+        if fresh:
+            # training: the workspace holds the activations saved for backward and is owned by
+            # the autograd node, so a second forward cannot overwrite it
             ws = ops.workspace(nbytes, device)
-            self._ws[key] = ws
+        else:
+            key = (str(device), nbytes)
+            ws = self._ws.get(key)
+            if ws is None:
+                self._ws.clear()
+                ws = ops.workspace(nbytes, device)
+                self._ws[key] = ws
         d.workspace = ws.data_ptr()
         d.workspace_bytes = nbytes
+        return ws
+
+    def _bwd_workspace(self, nbytes, device):
+        key = ("bwd", str(device), nbytes)
+        ws = self._ws.get(key)
+        if ws is None:
+            for k in [k for k in self._ws if k[0] == "bwd"]:
+                del self._ws[k]
+            ws = ops.workspace(nbytes, device)
+            self._ws[key] = ws
         return ws
 
     def forward(self, rain_lr, dem, lu, input_grid_size=None):
@@ -256,7 +274,7 @@ class Generator(nn.Module):
     def _forward_impl(self, rain_lr, dem, lu, input_grid_size, save_for_backward):
         d, _ = self._describe(rain_lr, dem, lu, input_grid_size, save_for_backward)
         out = torch.empty((d.B, d.T, 1, d.out_H, d.out_W), dtype=torch.float32, device=rain_lr.device)
-        ws = self._workspace(d, rain_lr.device)
+        ws = self._workspace(d, rain_lr.device, fresh=save_for_backward)
         self._bind(d, rain_lr, dem, lu, out)
         rc = _lib.lib().plc_generator_rollout_fwd(C.byref(d), ops._stream())
         _lib.check(rc, "plc_generator_rollout_fwd")

@@ -56,6 +56,27 @@ def convlstm_cell_forward(x, h, c, weight, bias):
     return h2, c2
 
 
+def convlstm_cell_backward(x, h, c, weight, bias, dh_next, dc_next):
+    """Gradients of ConvLSTMCell.forward: returns (dx, dh, dc, dweight, dbias)."""
+    L = _lib.lib()
+    x, h, c, weight = (_require_dev(t, n) for t, n in ((x, "x"), (h, "h_cur"), (c, "c_cur"), (weight, "weight")))
+    dh_next = _require_dev(dh_next, "dh_next")
+    dc_next = _require_dev(dc_next, "dc_next")
+    B, Cin, H, W = x.shape
+    Ch = h.shape[1]
+    dx, dh, dc = torch.empty_like(x), torch.empty_like(h), torch.empty_like(c)
+    dw = torch.empty_like(weight)
+    db = torch.empty(4 * Ch, dtype=torch.float32, device=x.device)
+    nbytes = L.plc_convlstm_cell_bwd_workspace_bytes(B, Cin, Ch, H, W)
+    ws = workspace(nbytes, x.device)
+    bias_p = _require_dev(bias, "bias").data_ptr() if bias is not None else None
+    rc = L.plc_convlstm_cell_bwd(x.data_ptr(), h.data_ptr(), c.data_ptr(), weight.data_ptr(), bias_p,
+                                 dh_next.data_ptr(), dc_next.data_ptr(), dx.data_ptr(), dh.data_ptr(), dc.data_ptr(),
+                                 dw.data_ptr(), db.data_ptr(), ws.data_ptr(), nbytes, B, Cin, Ch, H, W, _stream())
+    _lib.check(rc, "plc_convlstm_cell_bwd")
+    return dx, dh, dc, dw, (db if bias is not None else None)
+
+
 def to_cb8_bf16(x: torch.Tensor) -> torch.Tensor:
     """NCHW fp32 -> CB8 bf16 [N][ceil(C/8)][H][W][8] (returned as an int16 tensor)."""
     L = _lib.lib()
