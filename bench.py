@@ -1,13 +1,17 @@
 #!/usr/bin/env python3
 """Benchmark of the ConvLSTM rollout hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--mode fwd] [--config c3|c2|c1|p2]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--mode train|fwd] [--config c3|c2|c1|c4|p2]
 
-One "step" = one pass of the hot path (the Generator rollout) over one batch of synthetic,
-HBM-resident input.  The default workload is the per-GPU shard of BASELINE.json configs[2]
-(256x256 frames, T=10, global batch 32 on 8 GPUs = 4 per GPU, scale_factor=1): the batch is
-sharded over ranks with no data-path collective in the forward pass, so scaling is weak
-(per-GPU work fixed).  Rank 0 prints ONE JSON line.
+One "step" = one pass of the hot path over one batch of synthetic, HBM-resident input:
+  train (default): zero_grad -> Generator rollout forward -> CombinedLoss -> backward (BPTT)
+                   -> gradient all-reduce (N > 1) -> clip_grad_norm(0.5) -> Adam step
+                   (the reference's step, src/training/trainer.py:290-315)
+  fwd:             the rollout forward under no_grad (inference)
+The default workload is the per-GPU shard of BASELINE.json configs[2] (256x256 frames, T=10,
+global batch 32 on 8 GPUs = 4 per GPU, scale_factor=1): the batch is sharded over ranks, the
+only collective is the gradient all-reduce, per-GPU work is fixed (weak scaling).
+Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
@@ -31,7 +35,9 @@ CONFIGS = {
 }
 FLOP_PER_PX_FWD = 171104          # algorithmic forward FLOPs per output pixel per frame (scale 1, L=5)
 CELL2_FLOP_PER_PX = 2 * 55296     # cell-2 gate conv: (16+32)*9*128 MACs per pixel
+CELL2_BYTES_PER_PX = 416          # x 32 + h 64 + c 128 read, h' 64 + c' 128 written (bf16 h, fp32 c)
 PEAK_BF16 = 2.5e15                # dense bf16 MFMA peak of MI355X, FLOP/s
+N_STATIONS = 35
 
 
 def synthetic(B, T, H, W, s, seed, device):
@@ -40,7 +46,9 @@ def synthetic(B, T, H, W, s, seed, device):
     dem = torch.rand(B, 1, H * s, W * s, generator=g)
     lu = torch.nn.functional.one_hot(torch.randint(0, 5, (B, H * s, W * s), generator=g), 5)
     lu = lu.permute(0, 3, 1, 2).float().contiguous()
-    return rain.to(device), dem.to(device), lu.to(device)
+    coords = torch.randint(0, min(H, W), (N_STATIONS, 2), generator=g).unsqueeze(0).repeat(B, 1, 1)
+    values = 20 * torch.rand(B, T, N_STATIONS, generator=g)
+    return tuple(t.to(device) for t in (rain, dem, lu, coords, values))
 
 
 def time_cell2_kernel(B, H, W, device, iters=50):
@@ -49,8 +57,9 @@ def time_cell2_kernel(B, H, W, device, iters=50):
     from pl_convlstm_gan_amd import _lib, ops
     L = _lib.lib()
     hw = H * W
-    x = torch.randint(-2 ** 15, 2 ** 15 - 1, (B * 2 * hw * 8,), dtype=torch.int16, device=device) & 0x3FFF
-    h = torch.randint(-2 ** 15, 2 ** 15 - 1, (B * 4 * hw * 8,), dtype=torch.int16, device=device) & 0x3FFF
+    x = torch.randn(B, 16, H, W, device=device)
+    h = torch.tanh(torch.randn(B, 32, H, W, device=device))
+    x8, h8 = ops.to_cb8_bf16(x), ops.to_cb8_bf16(h)
     c = torch.randn(B * 32 * hw, device=device)
     w = 0.05 * torch.randn(128, 48, 3, 3, device=device)
     b = torch.zeros(128, device=device)
@@ -58,11 +67,11 @@ def time_cell2_kernel(B, H, W, device, iters=50):
     bpk = torch.empty(L.plc_packed_bias_bytes(128), dtype=torch.uint8, device=device)
     st = ops._stream()
     _lib.check(L.plc_pack_conv_weight(w.data_ptr(), b.data_ptr(), wpk.data_ptr(), bpk.data_ptr(), 128, 16, 32, 3, 1, st), "pack")
-    ho = torch.empty_like(h)
+    ho = torch.empty_like(h8)
     co = torch.empty_like(c)
 
     def run():
-        _lib.check(L.plc_convlstm_cell_fwd_cb8(x.data_ptr(), h.data_ptr(), c.data_ptr(), wpk.data_ptr(), bpk.data_ptr(),
+        _lib.check(L.plc_convlstm_cell_fwd_cb8(x8.data_ptr(), h8.data_ptr(), c.data_ptr(), wpk.data_ptr(), bpk.data_ptr(),
                                                ho.data_ptr(), co.data_ptr(), None, B, 16, 32, H, W, st), "cell2")
     for _ in range(5):
         run()
@@ -76,29 +85,40 @@ def time_cell2_kernel(B, H, W, device, iters=50):
     return e0.elapsed_time(e1) * 1e-3 / iters
 
 
-def cpu_baseline(B, T, H, W, s, params):
-    """The CPU oracle (a port of the reference forward) timed on this host, best of 3."""
+def cpu_baseline(mode, B, T, H, W, s, params):
+    """The CPU oracle (a port of the reference) timed on this host: best of 3 on a bounded sample
+    (one batch element of the per-GPU workload when training, the full shard for inference)."""
     from oracle import cpu_oracle as O
     threads = min(16, os.cpu_count() or 1)
     torch.set_num_threads(threads)
-    rain, dem, lu = synthetic(B, T, H, W, s, 99, "cpu")
-    with torch.no_grad():
-        O.generator_forward(params, rain[:1, :1], dem[:1], lu[:1], scale_factor=s)
-        best = float("inf")
+    Bc = 1 if mode == "train" else B
+    rain, dem, lu, coords, values = synthetic(Bc, T, H, W, s, 99, "cpu")
+    best = float("inf")
+    if mode == "train":
+        O.grads_of(params, rain[:, :2], dem, lu, coords, values[:, :2], fwd_kw=dict(scale_factor=s))
         for _ in range(3):
             t0 = time.perf_counter()
-            O.generator_forward(params, rain, dem, lu, scale_factor=s)
+            O.grads_of(params, rain, dem, lu, coords, values, fwd_kw=dict(scale_factor=s))
             best = min(best, time.perf_counter() - t0)
-    return {"value": B * T / best, "unit": "frames/s", "cores": threads, "kind": "port",
-            "sample": f"full per-GPU workload B={B},T={T},{H * s}x{W * s}, fp32 PyTorch-CPU oracle forward, best of 3"}
+        what = "forward + CombinedLoss + autograd backward (no optimizer)"
+    else:
+        with torch.no_grad():
+            O.generator_forward(params, rain[:1, :1], dem[:1], lu[:1], scale_factor=s)
+            for _ in range(3):
+                t0 = time.perf_counter()
+                O.generator_forward(params, rain, dem, lu, scale_factor=s)
+                best = min(best, time.perf_counter() - t0)
+        what = "forward"
+    return {"value": Bc * T / best, "unit": "frames/s", "cores": threads, "kind": "port",
+            "sample": f"B={Bc} of the per-GPU workload (T={T}, {H * s}x{W * s}), fp32 PyTorch-CPU oracle {what}, best of 3"}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--mode", default="fwd", choices=["fwd"])
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--mode", default="train", choices=["train", "fwd"])
     ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -115,20 +135,25 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     from pl_convlstm_gan_amd import Generator
+    from pl_convlstm_gan_amd.losses import CombinedLoss
+    from pl_convlstm_gan_amd.training import train_step
+
     B, T, H, W, s = CONFIGS[args.config]
-    torch.manual_seed(0)
+    torch.manual_seed(0)                       # identical initial weights on every rank
     model = Generator(hidden_dims=[16, 32], lu_channels=5, scale_factor=s)
-    rain, dem, lu = synthetic(B, T, H, W, s, 1234 + rank, device)
+    rain, dem, lu, coords, values = synthetic(B, T, H, W, s, 1234 + rank, device)
     model = model.to(device)
     with torch.no_grad():
         model(rain[:1, :1].contiguous(), dem[:1].contiguous(), lu[:1].contiguous())   # materialise lazy blocks
+    loss_module = CombinedLoss()
+    opt = torch.optim.Adam(model.parameters(), lr=5e-4)
 
-    def step():
+    def step_train():
+        return train_step(model, loss_module, opt, rain, dem, lu, coords, values, max_norm=0.5)[0]
+
+    def step_fwd():
         with torch.no_grad():
             return model(rain, dem, lu)
-
-    for _ in range(args.warmup):
-        step()
 
     def barrier():
         torch.cuda.synchronize()
@@ -136,31 +161,42 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], device=device, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-    assert torch.isfinite(out).all()
+    def timed(fn, steps, warmup):
+        for _ in range(warmup):
+            fn()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            last = fn()
+        barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([dt], device=device, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        assert torch.isfinite(last.detach()).all()
+        return dt
+
+    main_fn = step_train if args.mode == "train" else step_fwd
+    dt = timed(main_fn, args.steps, args.warmup)
+    dt_fwd = timed(step_fwd, max(5, args.steps // 2), 2) if args.mode == "train" else dt
+    n_fwd = max(5, args.steps // 2) if args.mode == "train" else args.steps
 
     if rank == 0:
         frames = world * B * T * args.steps
-        ms = dt / args.steps * 1e3
+        what = ("train step (forward + CombinedLoss + BPTT backward + grad all-reduce + clip + Adam)"
+                if args.mode == "train" else "rollout forward (inference)")
         res = {
             "metric": "predicted frames/sec (whole node), BxTxCx256x256" if args.config in ("c3", "c4", "p2")
                       else "predicted frames/sec (whole node)",
             "value": frames / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"{args.config}: Generator rollout forward (inference), B={B}/GPU, T={T}, "
-                                   f"{H}x{W} -> {H * s}x{W * s}, 1 channel, hidden [16,32], L=5, scale_factor={s}",
+            "config": {"workload": f"{args.config}: {what}, B={B}/GPU, T={T}, {H}x{W} -> {H * s}x{W * s}, 1 channel, "
+                                   f"hidden [16,32], L=5, scale_factor={s}, {N_STATIONS} stations",
                        "global_batch": world * B, "T": T, "mode": args.mode,
-                       "parallelism": f"dp{world} (batch sharded, no forward collective)"},
+                       "parallelism": f"dp{world} (batch sharded; one flat-gradient all-reduce per step)"},
+            "fwd_frames_per_s": world * B * T * n_fwd / dt_fwd,
         }
         # dominant kernel: cell-2 gate conv, one launch per timestep
         tk = time_cell2_kernel(B, H, W, device)
@@ -173,13 +209,11 @@ def main():
                            "achieved": flops / tk / 1e12, "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
                            "frac": flops / tk / PEAK_BF16, "traffic": traffic,
                            "launch_us": tk * 1e6, "flop_per_launch": flops,
-                           "alg_bytes_per_launch": 416 * B * H * W,
-                           "hbm_frac": 416 * B * H * W / tk / 8e12}
-        if s == 1:
-            res["whole_path_tflops"] = frames / dt * FLOP_PER_PX_FWD * H * W / 1e12 / world
+                           "alg_bytes_per_launch": CELL2_BYTES_PER_PX * B * H * W,
+                           "hbm_frac": CELL2_BYTES_PER_PX * B * H * W / tk / 8e12}
         if not args.no_cpu_baseline and world == 1:
             params = {k: v.detach().cpu() for k, v in model.state_dict().items()}
-            res["cpu_baseline"] = cpu_baseline(B, T, H, W, s, params)
+            res["cpu_baseline"] = cpu_baseline(args.mode, B, T, H, W, s, params)
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -49,7 +49,7 @@ static int launch_wgrad(ConvArgs in, PlcTensor dz, int mcb_valid, int n_img, flo
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), G::LDS_BYTES, st, a);
     PLC_HIP(hipGetLastError());
     const long long total = (long long)cout * G::NT * 32;
-    hipLaunchKernelGGL(plc_wgrad_finalize_kernel, dim3(ew_grid(total)), dim3(256), 0, st, (const float*)slab, grid,
+    hipLaunchKernelGGL(plc_wgrad_finalize_kernel, dim3(ew_grid(total * 8)), dim3(256), 0, st, (const float*)slab, grid,
                        MT * 32, G::NT * 32, dw, db, cout, c0, c1, KS, NCB0 + NCB1);
     PLC_HIP(hipGetLastError());
     return PLC_OK;

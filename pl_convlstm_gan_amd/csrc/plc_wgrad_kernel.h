@@ -208,29 +208,36 @@ __global__ __launch_bounds__(512, 2) void plc_wgrad_kernel(const WgradArgs a) {
 __global__ void plc_wgrad_finalize_kernel(const float* __restrict__ slab, int n_slabs, int rows_pad, int cols_pad,
                                           float* __restrict__ dw, float* __restrict__ db, int cout, int c0, int c1,
                                           int ks, int ncb) {
+    // 256 threads = 32 consecutive output elements x 8 slab lanes; lane q sums slabs q, q+8, ...
+    // and the 8 partial sums are combined in a fixed order through LDS.
+    __shared__ float part[8][33];
     const int taps = ks * ks, ncbp = (ncb + 1) / 2;
     const long long total = (long long)cout * cols_pad;
-    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
-         idx += (long long)gridDim.x * blockDim.x) {
-        const int o = idx / cols_pad, ncol = idx % cols_pad;
-        const int grp = ncol >> 4, c16 = ncol & 15;
-        int ci = -1, tap = 0;
-        bool is_bias = false;
-        if (grp < taps * ncbp) {
-            tap = grp / ncbp;
-            const int cb = 2 * (grp % ncbp) + (c16 >> 3);
-            if (cb < ncb) ci = plc_padded_to_concat(cb, c16 & 7, c0, c1);
-        } else if (grp == taps * ncbp && c16 == 0) {
-            is_bias = true;
-        }
-        if (ci < 0 && !is_bias) continue;
+    const int el = threadIdx.x & 31, q = threadIdx.x >> 5;
+    for (long long base = (long long)blockIdx.x * 32; base < total; base += (long long)gridDim.x * 32) {
+        const long long idx = base + el;
         float s = 0.0f;
-        const float* p = slab + (long long)o * cols_pad + ncol;
-        for (int b = 0; b < n_slabs; ++b) s += p[(long long)b * rows_pad * cols_pad];
-        if (is_bias) {
-            if (db) db[o] = s;
-        } else {
-            dw[((long long)o * (c0 + c1) + ci) * taps + tap] = s;
+        if (idx < total) {
+            const float* p = slab + idx;   // slab row stride == cols_pad, so (o, ncol) sits at idx
+            for (int b = q; b < n_slabs; b += 8) s += p[(long long)b * rows_pad * cols_pad];
         }
+        part[q][el] = s;
+        __syncthreads();
+        if (q == 0 && idx < total) {
+            float t = part[0][el];
+#pragma unroll
+            for (int k = 1; k < 8; ++k) t += part[k][el];
+            const int o = idx / cols_pad, ncol = idx % cols_pad;
+            const int grp = ncol >> 4, c16 = ncol & 15;
+            if (grp < taps * ncbp) {
+                const int tap = grp / ncbp;
+                const int cb = 2 * (grp % ncbp) + (c16 >> 3);
+                const int ci = cb < ncb ? plc_padded_to_concat(cb, c16 & 7, c0, c1) : -1;
+                if (ci >= 0) dw[((long long)o * (c0 + c1) + ci) * taps + tap] = t;
+            } else if (grp == taps * ncbp && c16 == 0) {
+                if (db) db[o] = t;
+            }
+        }
+        __syncthreads();
     }
 }

@@ -1,0 +1,118 @@
+"""Multi-process (world_size 2, gloo, CPU) tests of the data-parallel step logic in
+pl_convlstm_gan_amd/training.py: flat-gradient all-reduce before the clip, collective NaN skip,
+identical parameters on every rank after a step.  The model here is a small CPU stand-in with
+the Generator's calling convention (the HIP rollout itself needs a GPU); what is under test is
+the exchange logic around it."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+import torch.nn as nn
+
+
+class TinyRollout(nn.Module):
+    """[B,T,1,H,W] -> [B,T,1,H,W]; same forward signature as Generator."""
+
+    def __init__(self):
+        super().__init__()
+        self.conv = nn.Conv2d(1, 1, 3, padding=1)
+        self.gate = nn.Conv2d(1 + 2, 1, 1)
+
+    def forward(self, rain_lr, dem, lu, input_grid_size=None):
+        B, T, C, H, W = rain_lr.shape
+        y = self.conv(rain_lr.reshape(B * T, C, H, W)).reshape(B, T, 1, H, W)
+        g = torch.sigmoid(self.gate(torch.cat((dem, lu), dim=1))).unsqueeze(1)
+        return y * g
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _batch(seed, B=2, T=3, H=6, W=5, N=4, nan=False):
+    g = torch.Generator().manual_seed(seed)
+    rain = torch.rand(B, T, 1, H, W, generator=g)
+    dem = torch.rand(B, 1, H, W, generator=g)
+    lu = torch.rand(B, 2, H, W, generator=g)
+    coords = torch.randint(0, min(H, W), (N, 2), generator=g).unsqueeze(0).repeat(B, 1, 1)
+    values = 5 * torch.rand(B, T, N, generator=g)
+    if nan:
+        values = values - 100.0     # log1p(<-1) -> NaN loss (reference quirk)
+    return rain, dem, lu, coords, values
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from pl_convlstm_gan_amd.losses import CombinedLoss
+    from pl_convlstm_gan_amd.training import train_step
+    torch.manual_seed(0)
+    model = TinyRollout()
+    opt = torch.optim.Adam(model.parameters(), lr=5e-4)
+    loss_mod = CombinedLoss()
+    # step 1: every rank has a different shard
+    l1, _, _, skipped1 = train_step(model, loss_mod, opt, *_batch(10 + rank), max_norm=0.5)
+    p1 = [p.detach().clone() for p in model.parameters()]
+    # step 2: rank 1's shard produces a NaN loss -> BOTH ranks must skip
+    l2, _, _, skipped2 = train_step(model, loss_mod, opt, *_batch(20 + rank, nan=(rank == 1)), max_norm=0.5)
+    p2 = [p.detach().clone() for p in model.parameters()]
+    torch.save({"skipped1": skipped1, "skipped2": skipped2, "p1": p1, "p2": p2, "l1": float(l1)},
+               os.path.join(out_dir, f"rank{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_dp_step_world2(tmp_path):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r = [torch.load(tmp_path / f"rank{i}.pt", weights_only=True) for i in range(world)]
+    assert r[0]["skipped1"] is False and r[1]["skipped1"] is False
+    assert r[0]["skipped2"] is True and r[1]["skipped2"] is True
+    for a, b in zip(r[0]["p1"], r[1]["p1"]):
+        assert torch.equal(a, b)                       # identical update on both ranks
+    for a, b in zip(r[0]["p1"], r[0]["p2"]):
+        assert torch.equal(a, b)                       # skipped step changed nothing
+
+    # single-process reference: the mean of the two shard gradients, clipped, one Adam step
+    from pl_convlstm_gan_amd.losses import CombinedLoss
+    torch.manual_seed(0)
+    model = TinyRollout()
+    opt = torch.optim.Adam(model.parameters(), lr=5e-4)
+    loss_mod = CombinedLoss()
+    grads = []
+    for rank in range(world):
+        model.zero_grad()
+        rain, dem, lu, coords, values = _batch(10 + rank)
+        out = model(rain, dem, lu)
+        loss, _ = loss_mod(out, rain, coords, values, 1.0)
+        loss.backward()
+        grads.append([p.grad.clone() for p in model.parameters()])
+    for p, g0, g1 in zip(model.parameters(), *grads):
+        p.grad = (g0 + g1) / 2
+    torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=0.5)
+    opt.step()
+    for p, q in zip(model.parameters(), r[0]["p1"]):
+        assert torch.allclose(p.detach(), q, atol=1e-7, rtol=1e-6)
+
+
+def test_bucket_roundtrip_and_clip():
+    from pl_convlstm_gan_amd.training import GradBucket, clip_flat_
+    m = TinyRollout()
+    for p in m.parameters():
+        p.grad = torch.randn_like(p)
+    ref = [p.grad.clone() for p in m.parameters()]
+    total = torch.sqrt(sum((g ** 2).sum() for g in ref))
+    b = GradBucket(m.parameters())
+    flat = b.gather()
+    assert flat.numel() == sum(p.numel() for p in m.parameters())
+    norm = clip_flat_(flat, 0.5)
+    b.scatter()
+    assert torch.allclose(norm, total)
+    coef = min(1.0, 0.5 / (float(total) + 1e-6))
+    for p, g in zip(m.parameters(), ref):
+        assert torch.allclose(p.grad, g * coef, atol=1e-7)
