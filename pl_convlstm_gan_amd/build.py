@@ -1,13 +1,14 @@
 """In-tree build of libplconvlstm.so with hipcc for gfx950 (cross-compiles without a GPU)."""
 from __future__ import annotations
 
+import glob
 import os
 import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "plc_api.hip")
 OUT = os.path.join(HERE, "libplconvlstm.so")
-DEPS = [SRC] + [os.path.join(HERE, "csrc", f) for f in ("plc_common.h", "plc_conv_kernel.h", "plc_misc_kernels.h")] + \
+DEPS = sorted(glob.glob(os.path.join(HERE, "csrc", "*.h")) + glob.glob(os.path.join(HERE, "csrc", "*.hip"))) + \
        [os.path.join(os.path.dirname(HERE), "include", "plconvlstm.h")]
 
 

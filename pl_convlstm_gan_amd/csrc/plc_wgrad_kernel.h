@@ -219,7 +219,17 @@ __global__ void plc_wgrad_finalize_kernel(const float* __restrict__ slab, int n_
         float s = 0.0f;
         if (idx < total) {
             const float* p = slab + idx;   // slab row stride == cols_pad, so (o, ncol) sits at idx
-            for (int b = q; b < n_slabs; b += 8) s += p[(long long)b * rows_pad * cols_pad];
+            const long long sstride = (long long)rows_pad * cols_pad;
+            for (int b0 = q; b0 < n_slabs; b0 += 64) {      // 8 independent loads in flight, fixed order
+                float v[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int b = b0 + 8 * k;
+                    v[k] = b < n_slabs ? __builtin_nontemporal_load(p + (long long)b * sstride) : 0.0f;
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) s += v[k];
+            }
         }
         part[q][el] = s;
         __syncthreads();
