@@ -86,7 +86,7 @@ __device__ __forceinline__ uint4 plc_stage_unit(const ConvArgs& a, const char* s
 // Epilogue of one pixel row of one 32-row output tile: acc register 4g+j = row 8g + 4*half + j.
 template <int EPI>
 __device__ __forceinline__ void plc_epilogue(const ConvArgs& a, const f32x16_t& acc, int n, int mt, int n_mt,
-                                             int gy, int gx, int half) {
+                                             int gy, int gx, int half, const float4& cp) {
     const int H = a.H, W = a.W;
     if (gy >= H || gx >= W) return;
     const long long pix = (long long)gy * W + gx;
@@ -94,7 +94,7 @@ __device__ __forceinline__ void plc_epilogue(const ConvArgs& a, const f32x16_t& 
     if (EPI == EPI_LSTM) {
         const long long coff = ((long long)mt * H * W + pix) * 32 + half * 16;
         const long long hoff = ((long long)mt * H * W + pix) * 16 + half * 8;
-        const float4 cp = *(const float4*)(plc_img(a.c_in, n, a.n_in) + coff);
+        // cp = previous cell state of this lane's 4 channels, fetched before the MFMA loop
         float ig[4], fg[4], og[4], gg[4], cn[4], hn[4];
         const float cpv[4] = {cp.x, cp.y, cp.z, cp.w};
 #pragma unroll
@@ -175,8 +175,12 @@ __device__ __forceinline__ void plc_epilogue(const ConvArgs& a, const f32x16_t& 
 // Dynamic LDS bytes of one instantiation.
 template <int NCB, int KS, int TH, int KSPLIT>
 constexpr int plc_conv_lds_bytes() {
-    return (NCB * (TH + 2 * (KS / 2)) * (32 + 2 * (KS / 2)) + (KSPLIT == 2 ? 4 * 4 * 64 : 0)) * 16;
+    // tile rounded up to whole 64-unit LDS-DMA pieces, then the K-split exchange buffer
+    return ((NCB * (TH + 2 * (KS / 2)) * (32 + 2 * (KS / 2)) + 63) / 64 * 64 + (KSPLIT == 2 ? 4 * 4 * 64 : 0)) * 16;
 }
+
+// source of out-of-image units for the LDS-DMA staging
+__device__ const uint4 plc_zero16 = {0u, 0u, 0u, 0u};
 
 template <int NCB0, int NCB1, int NMT, int KS, int STAGE, int EPI, int TH, int KSPLIT = 1>
 __global__ __launch_bounds__(256, 2) void plc_conv_mfma_kernel(const ConvArgs a) {
@@ -192,8 +196,8 @@ __global__ __launch_bounds__(256, 2) void plc_conv_mfma_kernel(const ConvArgs a)
     constexpr int RG = 4 / (NMT * KSPLIT);   // row groups (wave sets sharing one M tile)
     constexpr int RPW = TH / RG;             // rows per wave (per wave pair when KSPLIT == 2)
     // rows (N tiles) per pass: 4 accumulators, or 2 when the stationary weights already take
-    // more than ~100 VGPRs (a single 32x32x16 accumulation chain issues back to back anyway)
-    constexpr int NREP_MAX = (KSPLIT == 2 || NKS * 4 > 100) ? 2 : 4;
+    // more than 64 VGPRs (a single 32x32x16 accumulation chain issues back to back anyway)
+    constexpr int NREP_MAX = (KSPLIT == 2 || NKS * 4 > 64) ? 2 : 4;
     constexpr int NREP = RPW < NREP_MAX ? RPW : NREP_MAX;
     constexpr int PASSES = RPW / NREP;
     static_assert(KSPLIT == 1 || KSPLIT == 2, "KSPLIT must be 1 or 2");
@@ -202,9 +206,11 @@ __global__ __launch_bounds__(256, 2) void plc_conv_mfma_kernel(const ConvArgs a)
     static_assert(RPW >= 1 && RPW % NREP == 0, "tile rows must split evenly over waves");
     static_assert(KSPLIT == 1 || NREP == 2, "K split needs two rows per pass");
     constexpr int RED_UNITS = KSPLIT == 2 ? 4 * 4 * 64 : 0;   // partial-sum exchange, 16 B units
-    static_assert((NCB * PLANE + RED_UNITS) * 16 <= 160 * 1024, "LDS tile too large");
+    constexpr int TILE_UNITS = (NCB * PLANE + 63) / 64 * 64;   // whole 64-unit DMA pieces
+    static_assert((TILE_UNITS + RED_UNITS) * 16 <= 160 * 1024, "LDS tile too large");
+    static_assert((TILE_UNITS + RED_UNITS) * 16 == plc_conv_lds_bytes<NCB, KS, TH, KSPLIT>(), "LDS size mismatch");
 
-    extern __shared__ __attribute__((aligned(16))) uint4 tile[];   // (NCB * PLANE + RED_UNITS) units
+    extern __shared__ __attribute__((aligned(16))) uint4 tile[];   // TILE_UNITS + RED_UNITS units
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -238,30 +244,86 @@ __global__ __launch_bounds__(256, 2) void plc_conv_mfma_kernel(const ConvArgs a)
         const char* s0 = plc_img(a.src0, n, a.n_in);
         const char* s1 = NCB1 > 0 ? plc_img(a.src1, n, a.n_in) : nullptr;
         const char* gt = STAGE == STAGE_CB8_GATED ? plc_img(a.gate, n, a.n_in) : nullptr;
-        for (int u = tid; u < NCB * PLANE; u += 256) {
-            const int cb = u / PLANE;
-            const int r = u - cb * PLANE;
-            const int ly = r / LW;
-            const int lx = r - ly * LW;
-            tile[u] = plc_stage_unit<STAGE, NCB0>(a, s0, s1, gt, cb, y0 - PAD + ly, x0 - PAD + lx, H, W);
+        if constexpr (STAGE == STAGE_CB8) {
+            // LDS-DMA: each wave instruction moves 64 consecutive units (1 KiB) straight from
+            // global memory into the tile, no VGPRs and no ds_write; out-of-image units read a
+            // 16-byte block of zeros instead.  All of a wave's pieces are in flight together.
+            constexpr int NCHUNK = TILE_UNITS / 64;
+            const long long plane_b = (long long)H * W * 16;
+            const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+            for (int ch = wave_u; ch < NCHUNK; ch += 4) {
+                const int u = ch * 64 + lane;
+                const int cb = u / PLANE;
+                const int r = u - cb * PLANE;
+                const int ly = r / LW;
+                const int lx = r - ly * LW;
+                const int gy = y0 - PAD + ly, gx = x0 - PAD + lx;
+                const bool ok = (cb < NCB) & (gy >= 0) & (gy < H) & (gx >= 0) & (gx < W);
+                const char* base = (cb < NCB0) ? (s0 + cb * plane_b) : (s1 + (cb - NCB0) * plane_b);
+                const char* src = ok ? base + ((long long)gy * W + gx) * 16 : (const char*)&plc_zero16;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(tile + ch * 64), 16, 0, 0);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            // register staging (the unit needs arithmetic): four independent units in flight
+            constexpr int NIT = (NCB * PLANE + 255) / 256;
+            for (int i0 = 0; i0 < NIT; i0 += 4) {
+                uint4 v[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int u = tid + (i0 + k) * 256;
+                    const int cb = u / PLANE;
+                    const int r = u - cb * PLANE;
+                    const int ly = r / LW;
+                    const int lx = r - ly * LW;
+                    v[k] = make_uint4(0, 0, 0, 0);
+                    if (u < NCB * PLANE)
+                        v[k] = plc_stage_unit<STAGE, NCB0>(a, s0, s1, gt, cb, y0 - PAD + ly, x0 - PAD + lx, H, W);
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int u = tid + (i0 + k) * 256;
+                    if (u < NCB * PLANE) tile[u] = v[k];
+                }
+            }
         }
     }
     __syncthreads();
 
     const char* lds = (const char*)tile;
-    const float4* bias4 = (const float4*)a.bpk + mt * 8;
+    float4 bv[4];   // bias of this lane's 16 rows (accumulator initial value)
+    {
+        const float4* bias4 = (const float4*)a.bpk + mt * 8;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            // the K-split instantiations are the bias-free data-gradient convs
+            bv[g] = KSPLIT == 2 ? make_float4(0.f, 0.f, 0.f, 0.f) : bias4[2 * g + half];
+        }
+        // retire these loads here: a load still pending at the loop head would make the compiler
+        // wait vmcnt(0) before the first MFMA of every pass, i.e. also for the prefetch issued there
+#pragma unroll
+        for (int g = 0; g < 4; ++g) asm volatile("" : "+v"(bv[g].x), "+v"(bv[g].y), "+v"(bv[g].z), "+v"(bv[g].w));
+    }
 
 #pragma unroll 1
     for (int pass = 0; pass < PASSES; ++pass) {
         const int row0 = rg * RPW + pass * NREP;
+        // the epilogue's global operand (previous cell state) is requested now so that its
+        // latency is covered by the MFMA loop
+        float4 cpre[NREP];
+#pragma unroll
+        for (int r = 0; r < NREP; ++r) {
+            cpre[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if constexpr (EPI == EPI_LSTM) {
+                const int gy = y0 + row0 + r, gx = x0 + px;
+                if (gy < H && gx < W)
+                    cpre[r] = *(const float4*)(plc_img(a.c_in, n, a.n_in) +
+                                               ((long long)mt * H * W + (long long)gy * W + gx) * 32 + half * 16);
+            }
+        }
         f32x16_t acc[NREP];
         {
-            float4 bv[4];
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                bv[g] = bias4[2 * g + half];
-                if (KSPLIT == 2 && ks != 0) bv[g] = make_float4(0.f, 0.f, 0.f, 0.f);
-            }
 #pragma unroll
             for (int r = 0; r < NREP; ++r)
 #pragma unroll
@@ -279,6 +341,39 @@ __global__ __launch_bounds__(256, 2) void plc_conv_mfma_kernel(const ConvArgs a)
             abase[r] = ((row0 + r) * LW + px) * 16 + ks * NCBW * PLANE * 16;
             if (NCBW % 2 == 0) abase[r] += half * PLANE * 16;
         }
+        if constexpr (NCBW % 2 == 0) {
+            // Fragment-centric, software-pipelined K loop.  The B fragment at LDS row rho, column
+            // shift dx, channel-block pair cbp feeds output row r with tap row dy = rho - r, so
+            // each fragment is read once and used by up to KS of the NREP accumulators.  Reads
+            // run DEPTH fragments ahead of the MFMAs that consume them (the LDS latency is several
+            // MFMA issue slots); sched_barrier pins that order, the compiler inserts the counted
+            // lgkmcnt waits.
+            constexpr int NCBP = NCBW / 2, ROWS = NREP + KS - 1, NF = ROWS * KS * NCBP;
+            constexpr int DEPTH = NF < 6 ? NF : 6;
+            bf16x8_t fr[NF];
+            const char* fbase = lds + abase[0];
+#pragma unroll
+            for (int f = 0; f < DEPTH; ++f) {
+                const int rho = f / (KS * NCBP), cbp = (f % (KS * NCBP)) / KS, dx = f % KS;
+                fr[f] = *(const bf16x8_t*)(fbase + ((rho * LW + dx) + cbp * 2 * PLANE) * 16);
+            }
+#pragma unroll
+            for (int f = 0; f < NF; ++f) {
+                if (f + DEPTH < NF) {
+                    const int g = f + DEPTH;
+                    const int rho = g / (KS * NCBP), cbp = (g % (KS * NCBP)) / KS, dx = g % KS;
+                    fr[g] = *(const bf16x8_t*)(fbase + ((rho * LW + dx) + cbp * 2 * PLANE) * 16);
+                }
+                const int rho = f / (KS * NCBP), cbp = (f % (KS * NCBP)) / KS, dx = f % KS;
+#pragma unroll
+                for (int r = 0; r < NREP; ++r) {
+                    const int dy = rho - r;
+                    if (dy >= 0 && dy < KS)
+                        acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[(dy * KS + dx) * NCBP + cbp], fr[f], acc[r], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else
 #pragma unroll
         for (int s = 0; s < NKS; ++s) {
             // unit u = tap * NCBW + cb; lanes 0-31 take unit 2s, lanes 32-63 unit 2s+1
@@ -299,7 +394,7 @@ __global__ __launch_bounds__(256, 2) void plc_conv_mfma_kernel(const ConvArgs a)
 
         if constexpr (KSPLIT == 2) {
             // exchange partial sums: wave ks finishes row ks of the pass, its partner the other row
-            float4* red = (float4*)(tile + NCB * PLANE);
+            float4* red = (float4*)(tile + TILE_UNITS);
             float4* mine = red + wave * 256 + lane;
             const float4* theirs = red + (wave ^ NMT) * 256 + lane;
             if (ks == 0) {
@@ -318,7 +413,7 @@ __global__ __launch_bounds__(256, 2) void plc_conv_mfma_kernel(const ConvArgs a)
                     const float4 t = theirs[g * 64];
                     acc[0][4 * g] += t.x; acc[0][4 * g + 1] += t.y; acc[0][4 * g + 2] += t.z; acc[0][4 * g + 3] += t.w;
                 }
-                plc_epilogue<EPI>(a, acc[0], n, mt, n_mt, y0 + row0, x0 + px, half);
+                plc_epilogue<EPI>(a, acc[0], n, mt, n_mt, y0 + row0, x0 + px, half, cpre[0]);
             } else {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
@@ -326,13 +421,13 @@ __global__ __launch_bounds__(256, 2) void plc_conv_mfma_kernel(const ConvArgs a)
                     acc[NREP - 1][4 * g] += t.x; acc[NREP - 1][4 * g + 1] += t.y;
                     acc[NREP - 1][4 * g + 2] += t.z; acc[NREP - 1][4 * g + 3] += t.w;
                 }
-                plc_epilogue<EPI>(a, acc[NREP - 1], n, mt, n_mt, y0 + row0 + 1, x0 + px, half);
+                plc_epilogue<EPI>(a, acc[NREP - 1], n, mt, n_mt, y0 + row0 + 1, x0 + px, half, cpre[NREP - 1]);
             }
             __syncthreads();   // the exchange buffer is reused by the next pass
         } else {
 #pragma unroll
             for (int r = 0; r < NREP; ++r) {
-                plc_epilogue<EPI>(a, acc[r], n, mt, n_mt, y0 + row0 + r, x0 + px, half);
+                plc_epilogue<EPI>(a, acc[r], n, mt, n_mt, y0 + row0 + r, x0 + px, half, cpre[r]);
                 __builtin_amdgcn_sched_barrier(0);  // keep the NREP epilogues from interleaving (register pressure)
             }
         }
