@@ -193,8 +193,12 @@ static int cell_fwd_cb8(const void* x, const void* h, const float* c_in, const v
     a.save_gates = gates != nullptr;
     a.wpk = (const uint4*)wpk;
     a.bpk = bpk;
-    if (Cin == 16 && Ch == 16) return launch_conv<2, 2, 2, 3, STAGE_CB8, EPI_LSTM>(a, B, 1, st);
-    if (Cin == 16 && Ch == 32) return launch_conv<2, 4, 4, 3, STAGE_CB8, EPI_LSTM>(a, B, 1, st);
+    if (Cin == 16 && Ch == 16)
+        return gates ? launch_conv<2, 2, 2, 3, STAGE_CB8, EPI_LSTM_SAVE>(a, B, 1, st)
+                     : launch_conv<2, 2, 2, 3, STAGE_CB8, EPI_LSTM>(a, B, 1, st);
+    if (Cin == 16 && Ch == 32)
+        return gates ? launch_conv<2, 4, 4, 3, STAGE_CB8, EPI_LSTM_SAVE>(a, B, 1, st)
+                     : launch_conv<2, 4, 4, 3, STAGE_CB8, EPI_LSTM>(a, B, 1, st);
     return plc_fail(PLC_EUNSUPPORTED,
                     "ConvLSTM cell (Cin=%d, Ch=%d) is outside the compiled kernel set {(16,16), (16,32)}", Cin, Ch);
 }
