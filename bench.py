@@ -128,12 +128,24 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # PLC_BENCH_BACKEND=gloo is a rehearsal aid: several ranks share one GPU to exercise the
+    # multi-process control flow on a single-GPU box (numbers from it are meaningless)
+    backend = os.environ.get("PLC_BENCH_BACKEND", "nccl")
+    dev_index = local_rank % max(torch.cuda.device_count(), 1) if backend != "nccl" else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
+    def dbg(msg):
+        if os.environ.get("PLC_BENCH_DEBUG"):
+            print(f"[rank {rank}] {msg}", file=sys.stderr, flush=True)
+
+    dbg("process group ready")
     from pl_convlstm_gan_amd import Generator
     from pl_convlstm_gan_amd.losses import CombinedLoss
     from pl_convlstm_gan_amd.training import train_step
@@ -147,6 +159,7 @@ def main():
         model(rain[:1, :1].contiguous(), dem[:1].contiguous(), lu[:1].contiguous())   # materialise lazy blocks
     loss_module = CombinedLoss()
     opt = torch.optim.Adam(model.parameters(), lr=5e-4)
+    dbg("model and data ready")
 
     def step_train():
         return train_step(model, loss_module, opt, rain, dem, lu, coords, values, max_norm=0.5)[0]
@@ -162,13 +175,16 @@ def main():
         torch.cuda.synchronize()
 
     def timed(fn, steps, warmup):
-        for _ in range(warmup):
+        for i in range(warmup):
             fn()
+            dbg(f"warmup step {i} done")
         barrier()
+        dbg("timed region starts")
         t0 = time.perf_counter()
         for _ in range(steps):
             last = fn()
         barrier()
+        dbg("timed region done")
         dt = time.perf_counter() - t0
         if world > 1:
             tt = torch.tensor([dt], device=device, dtype=torch.float64)
