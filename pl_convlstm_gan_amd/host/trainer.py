@@ -1,0 +1,251 @@
+"""Trainer with the reference's interface (src/training/trainer.py:16-449) on the HIP engine.
+
+Same constructor, attributes (config, device, output_dir, history, best_rmse, best_epoch,
+early_stopping, model, optimizer, scheduler, loss_module, train_loader / val_loader / test_loader /
+dataloader) and methods (setup_data, setup_model, validate, compute_station_rmse, train_epoch,
+train).  Additions: batch data parallelism when launched under torchrun (each rank trains on
+its shard of every batch; one flat-gradient all-reduce per step, see training.py), and
+``resume(path)`` (the reference only saves).
+
+Kept from the reference on purpose: the optimizer is built before the generator's lazy upsample
+blocks exist, so those blocks receive gradients and count in the clip norm but are not updated
+(set ``optimize_lazy_blocks = True`` before ``train()`` to register them after the first forward);
+ReduceLROnPlateau steps on the validation RMSE; only the best model is saved.
+"""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+import torch
+import torch.distributed as dist
+from torch.utils.data import DataLoader
+
+from ..losses import CombinedLoss
+from ..models import Generator
+from ..training import train_step
+from .config import load_config
+from .datasets import FenheDataset, split_dataset_by_year, split_dataset_random
+from .early_stopping import EarlyStopping
+
+HISTORY_KEYS = ("epoch", "total_loss", "point_loss", "conserve_loss", "smooth_loss", "temporal_loss", "rmse",
+                "learning_rate")
+
+
+def _rank_world():
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+class Trainer:
+    def __init__(self, config_name="default"):
+        self.config = load_config(config_name)
+        self.device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
+        self.output_dir = self.config.output.output_dir
+        os.makedirs(self.output_dir, exist_ok=True)
+        self.history = {k: [] for k in HISTORY_KEYS}
+        self.best_rmse = float("inf")
+        self.best_epoch = -1
+        self.optimize_lazy_blocks = False
+        self.early_stopping = None
+        tr = self.config.training
+        if getattr(tr, "use_early_stopping", False):
+            self.early_stopping = EarlyStopping(patience=getattr(tr, "early_stopping_patience", 20),
+                                                min_delta=getattr(tr, "early_stopping_min_delta", 0.0001),
+                                                mode="min", verbose=True)
+
+    # ------------------------------------------------------------------ data
+    def setup_data(self):
+        d, tr = self.config.data, self.config.training
+        full = FenheDataset(rain_lr_path=d.rain_lr_path, dem_path=d.dem_path, lucc_path=d.lucc_path,
+                            rain_meta_path=d.meta_path, rain_station_path=d.rain_excel_path, shp_path=d.shp_path,
+                            T=self.config.model.T, start_year=d.start_year, end_year=d.end_year)
+        if tr.use_split:
+            if tr.split_method == "year":
+                parts = split_dataset_by_year(full, tuple(tr.train_years), tuple(tr.val_years), tuple(tr.test_years))
+            else:
+                parts = split_dataset_random(full, 0.7, 0.15, 0.15)
+            self.train_loader = DataLoader(parts[0], batch_size=tr.batch_size, shuffle=True)
+            self.val_loader = DataLoader(parts[1], batch_size=tr.batch_size, shuffle=False)
+            self.test_loader = DataLoader(parts[2], batch_size=tr.batch_size, shuffle=False)
+        else:
+            self.train_loader = DataLoader(full, batch_size=tr.batch_size, shuffle=True)
+            self.val_loader = self.test_loader = None
+        self.dataloader = self.train_loader
+        return full
+
+    # ------------------------------------------------------------------ model
+    def setup_model(self, dataset):
+        onehot = dataset.lucc_onehot_list[0] if getattr(dataset, "is_multiyear_lucc", False) else dataset.lucc_onehot
+        kw = {"hidden_dims": self.config.model.hidden_dims, "lu_channels": onehot.shape[0]}
+        mc = self.config.model
+        if getattr(mc, "target_grid_size", None):
+            kw["target_grid_size"] = tuple(mc.target_grid_size)
+        elif getattr(mc, "scale_factor", None):
+            kw["scale_factor"] = mc.scale_factor
+        rank, world = _rank_world()
+        if world > 1:
+            torch.manual_seed(0)      # identical initial weights on every rank
+        self.model = Generator(**kw).to(self.device)
+        tr = self.config.training
+        self.optimizer = torch.optim.Adam(self.model.parameters(), lr=tr.learning_rate)
+        self.scheduler = torch.optim.lr_scheduler.ReduceLROnPlateau(self.optimizer, mode="min", factor=tr.scheduler_factor,
+                                                                    patience=tr.scheduler_patience)
+        self.loss_module = CombinedLoss(lambda_point=tr.lambda_point, lambda_conserve=tr.lambda_conserve,
+                                        lambda_smooth=tr.lambda_smooth, lambda_temporal=tr.lambda_temporal,
+                                        use_weighted_loss=getattr(tr, "use_weighted_loss", True),
+                                        weight_strategy=getattr(tr, "weight_strategy", "log"))
+
+    def _forward_kwargs(self):
+        igs = getattr(self.config.model, "input_grid_size", None)
+        return {"input_grid_size": tuple(igs)} if igs else {}
+
+    def _to_device(self, batch):
+        return tuple(t.to(self.device) for t in batch)
+
+    def _shard(self, batch):
+        """This rank's slice of a batch (data parallelism; identity for a single process)."""
+        rank, world = _rank_world()
+        if world == 1:
+            return batch
+        n = batch[0].shape[0]
+        lo, hi = rank * n // world, (rank + 1) * n // world
+        return tuple(t[lo:hi] for t in batch)
+
+    # ------------------------------------------------------------------ evaluation
+    def compute_station_rmse(self, fake_hr, s_coords, s_values, scale_factor=1.0):
+        """(rmse, pred_at_stations, true_vals, valid_station_mask, mask): trainer.py:225-272."""
+        B, T, _, H, W = fake_hr.shape
+        coords = s_coords[0] if s_coords.dim() == 3 else s_coords
+        hr = ((coords.float() + 0.5) * scale_factor - 0.5).long()
+        rows, cols = hr[:, 0], hr[:, 1]
+        inside = (rows >= 0) & (rows < H) & (cols >= 0) & (cols < W)
+        zero = torch.tensor(0.0, device=fake_hr.device)
+        if int(inside.sum()) == 0:
+            return zero, None, None, inside, None
+        at = fake_hr[:, :, 0][:, :, rows[inside], cols[inside]]
+        truth = s_values[:, :, inside]
+        seen = ~torch.isnan(truth)
+        rmse = torch.sqrt(((at[seen] - truth[seen]) ** 2).mean()) if int(seen.sum()) > 0 else zero
+        return rmse, at, truth, inside, seen
+
+    def validate(self):
+        if self.val_loader is None:
+            return None
+        self.model.eval()
+        losses, rmses = [], []
+        with torch.no_grad():
+            for batch in self.val_loader:
+                lr, dem, lu, s_coords, s_values = self._to_device(batch)
+                fake_hr = self.model(lr, dem, lu, **self._forward_kwargs())
+                sf = fake_hr.shape[-2] / lr.shape[-2]
+                loss, _ = self.loss_module(fake_hr, lr, s_coords, s_values, sf)
+                losses.append(loss.item())
+                rmses.append(self.compute_station_rmse(fake_hr, s_coords, s_values, sf)[0].item())
+        self.model.train()
+        return {"loss": np.mean(losses), "rmse": np.mean(rmses)}
+
+    # ------------------------------------------------------------------ training
+    def train_epoch(self, epoch, T):
+        self.model.train()
+        rmses = []
+        sums = {k: [] for k in ("total", "point", "conserve", "smooth", "temporal")}
+        last = (None, None, None, None)
+        for i, batch in enumerate(self.train_loader):
+            lr, dem, lu, s_coords, s_values = self._shard(self._to_device(batch))
+            if lr.shape[0] == 0:
+                continue
+            loss, parts, fake_hr, skipped = train_step(
+                self.model, self.loss_module, self.optimizer, lr, dem, lu, s_coords, s_values,
+                max_norm=self.config.training.grad_clip_norm, forward_kwargs=self._forward_kwargs())
+            if self.optimize_lazy_blocks and self.model.upsample_blocks is not None and len(self.optimizer.param_groups) == 1 \
+                    and len(self.model.upsample_blocks) > 0:
+                self.optimizer.add_param_group({"params": list(self.model.upsample_blocks.parameters())})
+            if skipped:
+                print("NaN detected, skip this batch")
+                continue
+            sums["total"].append(loss.item())
+            for k in ("point", "conserve", "smooth", "temporal"):
+                sums[k].append(float(parts[k].detach()))
+            with torch.no_grad():
+                sf = fake_hr.shape[-2] / lr.shape[-2]
+                rmse, at, truth, inside, _ = self.compute_station_rmse(fake_hr.detach(), s_coords, s_values, sf)
+                rmses.append(rmse.item())
+                last = (at, truth, s_coords, inside)
+            if i % self.config.output.log_interval == 0 and _rank_world()[0] == 0:
+                print(f"Epoch {epoch} | Loss: {loss.item():.4f} | Point: {sums['point'][-1]:.4f} | "
+                      f"Conserve: {sums['conserve'][-1]:.4f} | Smooth: {sums['smooth'][-1]:.4f} | "
+                      f"Temporal: {sums['temporal'][-1]:.4f} | Batch RMSE: {rmse.item():.4f}")
+        avg = {k: (float(np.mean(v)) if v else 0.0) for k, v in sums.items()}
+        return rmses, last[0], last[1], last[2], last[3], avg
+
+    def _checkpoint(self, epoch, rmse):
+        path = os.path.join(self.output_dir, "best_model.pth")
+        if os.path.exists(path):
+            os.remove(path)
+        torch.save({"epoch": epoch, "model_state_dict": self.model.state_dict(),
+                    "optimizer_state_dict": self.optimizer.state_dict(),
+                    "scheduler_state_dict": self.scheduler.state_dict(), "rmse": rmse, "history": self.history}, path)
+        print(f"New best model saved: epoch {epoch + 1}, RMSE {rmse:.4f}")
+
+    def resume(self, path):
+        """Load a checkpoint written by ``train`` (not in the reference).  Needs setup_model first; the
+        lazy upsample blocks are materialised from the checkpoint's keys."""
+        from ..models import UpsampleBlock
+        ck = torch.load(path, map_location=self.device, weights_only=False)
+        n_blocks = len({k.split(".")[1] for k in ck["model_state_dict"] if k.startswith("upsample_blocks.")})
+        if self.model.upsample_blocks is None:
+            self.model.upsample_blocks = torch.nn.ModuleList(
+                [UpsampleBlock(self.model.hidden_dims[1], 2) for _ in range(n_blocks)]).to(self.device)
+        self.model.load_state_dict(ck["model_state_dict"])
+        self.optimizer.load_state_dict(ck["optimizer_state_dict"])
+        self.scheduler.load_state_dict(ck["scheduler_state_dict"])
+        self.history = ck["history"]
+        self.best_rmse, self.best_epoch = ck["rmse"], ck["epoch"]
+        return ck["epoch"] + 1
+
+    def train(self, start_epoch=0):
+        if not hasattr(self, "model"):
+            dataset = self.setup_data()
+            self.setup_model(dataset)
+        T = self.config.model.T
+        rank = _rank_world()[0]
+        for epoch in range(start_epoch, self.config.training.epochs):
+            rmses, at, truth, s_coords, inside, avg = self.train_epoch(epoch, T)
+            train_rmse = float(np.mean(rmses)) if rmses else float("nan")
+            self.history["epoch"].append(epoch)
+            for k in ("total", "point", "conserve", "smooth", "temporal"):
+                self.history[f"{k}_loss"].append(avg[k])
+            self.history["rmse"].append(train_rmse)
+            self.history["learning_rate"].append(self.optimizer.param_groups[0]["lr"])
+            val = self.validate()
+            current = val["rmse"] if val else train_rmse
+            if rank == 0:
+                print(f"Epoch {epoch} | Train RMSE: {train_rmse:.4f}" +
+                      (f" | Val Loss: {val['loss']:.4f} | Val RMSE: {val['rmse']:.4f}" if val else ""))
+            self.scheduler.step(current)
+            if (epoch + 1) % 10 == 0 and rank == 0:
+                self._plot_curves("training_curves.png")
+            if self.early_stopping is not None:
+                is_best = self.early_stopping(current, epoch)
+            else:
+                is_best = current < self.best_rmse
+            if is_best:
+                self.best_rmse, self.best_epoch = current, epoch
+                if rank == 0:
+                    self._checkpoint(epoch, current)
+            if self.early_stopping is not None and self.early_stopping.early_stop:
+                print(f"Early stop at epoch {epoch + 1}; best epoch {self.best_epoch + 1}, RMSE {self.best_rmse:.4f}")
+                break
+        if rank == 0:
+            self._plot_curves("final_training_curves.png")
+            print(f"Training completed. Best model: epoch {self.best_epoch + 1}, RMSE {self.best_rmse:.4f}; "
+                  f"results in {self.output_dir}/")
+
+    def _plot_curves(self, name):
+        try:
+            from .visualization import plot_training_curves
+            plot_training_curves(self.history, save_path=os.path.join(self.output_dir, name))
+        except Exception as exc:   # plotting is optional (matplotlib may be missing or headless)
+            print(f"(plot skipped: {exc})")
