@@ -19,12 +19,18 @@ __global__ void plc_plane_to_cb8_kernel(PlcTensor src, int n_in, int N, long lon
 // ---------------------------------------------------------------------------------------------
 // weight gradient launcher
 // ---------------------------------------------------------------------------------------------
-static const int WGRAD_MAX_BLOCKS = 256;   // one persistent workgroup per CU
+// Persistent workgroups per launch: one per CU when the LDS double buffer fills the CU, two when
+// two fit (the small-channel convs, whose per-tile MFMA work is shorter than a global-load round
+// trip: a second resident workgroup hides that latency).
+template <int NCB0, int NCB1, int MT, int KS>
+static constexpr int wgrad_max_blocks() {
+    return WgradGeom<NCB0 + NCB1, MT, KS>::LDS_BYTES <= 80 * 1024 ? 512 : 256;
+}
 
 template <int NCB0, int NCB1, int MT, int KS>
 static size_t wgrad_slab_bytes() {
     using G = WgradGeom<NCB0 + NCB1, MT, KS>;
-    return align256((size_t)WGRAD_MAX_BLOCKS * (MT * 32) * (G::NT * 32) * sizeof(float));
+    return align256((size_t)wgrad_max_blocks<NCB0, NCB1, MT, KS>() * (MT * 32) * (G::NT * 32) * sizeof(float));
 }
 
 // `in` carries H, W, n_in and the staging tensors of the conv input; dz has mcb_valid channel blocks.
@@ -43,7 +49,8 @@ static int launch_wgrad(ConvArgs in, PlcTensor dz, int mcb_valid, int n_img, flo
     a.mcb_valid = mcb_valid;
     a.n_tiles = n_img * a.in.tiles_x * a.in.tiles_y;
     a.slab = slab;
-    const int grid = a.n_tiles < WGRAD_MAX_BLOCKS ? a.n_tiles : WGRAD_MAX_BLOCKS;
+    constexpr int max_blocks = wgrad_max_blocks<NCB0, NCB1, MT, KS>();
+    const int grid = a.n_tiles < max_blocks ? a.n_tiles : max_blocks;
     auto kern = plc_wgrad_kernel<NCB0, NCB1, MT, KS, STAGE>;
     PLC_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), G::LDS_BYTES, st, a);

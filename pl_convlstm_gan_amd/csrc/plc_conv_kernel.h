@@ -215,8 +215,16 @@ constexpr int plc_conv_lds_bytes() {
 // source of out-of-image units for the LDS-DMA staging
 __device__ const uint4 plc_zero16 = {0u, 0u, 0u, 0u};
 
+// Waves per SIMD to compile for: three (three workgroups per CU) for the light convs, whose time is
+// load/store latency rather than MFMA issue; two when the stationary weights need the registers.
+template <int NCB, int KS, int KSPLIT, int NMT, int EPI>
+constexpr int plc_conv_min_waves() {
+    return (NMT == 1 && EPI != EPI_LSTM && EPI != EPI_LSTM_SAVE && ((KS * KS * (NCB / KSPLIT) + 1) / 2) * 4 <= 80) ? 3 : 2;
+}
+
 template <int NCB0, int NCB1, int NMT, int KS, int STAGE, int EPI, int TH, int KSPLIT = 1>
-__global__ __launch_bounds__(256, 2) void plc_conv_mfma_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(256, (plc_conv_min_waves<NCB0 + NCB1, KS, KSPLIT, NMT, EPI>()))
+void plc_conv_mfma_kernel(const ConvArgs a) {
     constexpr int NCB = NCB0 + NCB1;
     constexpr int NCBW = NCB / KSPLIT;       // channel blocks contracted by one wave
     constexpr int TAPS = KS * KS;
