@@ -183,6 +183,40 @@ typedef struct plc_rollout_grads {
 size_t plc_generator_bwd_workspace_bytes(const plc_rollout_desc* d);
 int plc_generator_rollout_bwd(const plc_rollout_desc* d, const plc_rollout_grads* g, void* stream);
 
+/* ---------------------------------------------------------------------------------------
+ * CombinedLoss and its gradient.  Replaces CombinedLoss.forward
+ * (src/losses/combined_loss.py:173-191) and the autograd backward of its four terms:
+ *   point     mean over observed gauges of |pred - obs| * weight(obs)   (combined_loss.py:79-141;
+ *             weights combined_loss.py:23-59; gauge pixel = trunc((coord + 0.5) * scale - 0.5))
+ *   conserve  mean |area_interpolate(pred -> LR grid) - lr_input|       (combined_loss.py:64-74)
+ *   smooth    mean|d/dx| + mean|d/dy|                                   (combined_loss.py:146-155)
+ *   temporal  mean|pred[t+1] - pred[t]|  (NaN when T == 1, as the reference) (combined_loss.py:160-168)
+ * One pass over pred produces the five scalars (device memory, no host sync) and, when
+ * grad_pred is given, d total / d pred.  Sums use a fixed reduction order (bit-repeatable).
+ * ------------------------------------------------------------------------------------- */
+enum { PLC_LOSS_W_NONE = 0, PLC_LOSS_W_LOG = 1, PLC_LOSS_W_SQRT = 2, PLC_LOSS_W_STRATIFIED = 3 };
+typedef struct plc_loss_desc {
+    int B, T;
+    int out_H, out_W;        /* pred is [B][T][1][out_H][out_W] */
+    int H, W;                /* lr_input is [B][T][1][H][W] */
+    int N;                   /* rain gauges; 0 = no gauge term (point = 0) */
+    int values_per_batch;    /* 1: s_values is [B][T][N]; 0: [T][N], shared by the batch */
+    int weight_mode;         /* PLC_LOSS_W_* (use_weighted_loss = False -> PLC_LOSS_W_NONE) */
+    float scale_factor;
+    float lambda_point, lambda_conserve, lambda_smooth, lambda_temporal;
+    const float* pred;
+    const float* lr_input;
+    const long long* s_coords;  /* int64 [N][2] (row, col) on the LR grid (sample 0's when batched) */
+    const float* s_values;      /* NaN = not observed */
+    float* losses;           /* [5]: total, point, conserve, smooth, temporal */
+    float* grad_pred;        /* NULL or [B][T][1][out_H][out_W], overwritten */
+    void* workspace;         /* plc_combined_loss_workspace_bytes(desc) bytes, 16-byte aligned */
+    size_t workspace_bytes;
+} plc_loss_desc;
+
+size_t plc_combined_loss_workspace_bytes(const plc_loss_desc* d);
+int plc_combined_loss(const plc_loss_desc* d, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -19,6 +19,7 @@ EXPORTS = (
     "plc_generator_workspace_bytes", "plc_generator_rollout_fwd", "plc_generator_workspace_offset",
     "plc_convlstm_cell_bwd_workspace_bytes", "plc_convlstm_cell_bwd",
     "plc_generator_bwd_workspace_bytes", "plc_generator_rollout_bwd",
+    "plc_combined_loss_workspace_bytes", "plc_combined_loss",
 )
 
 _f = C.c_void_p   # device pointers travel as plain addresses
@@ -54,6 +55,19 @@ class RolloutGrads(C.Structure):
         ("up_w", _f * 8), ("up_b", _f * 8),
         ("post0_w", _f), ("post0_b", _f), ("post2_w", _f), ("post2_b", _f),
         ("workspace", _f), ("workspace_bytes", C.c_size_t),
+    ]
+
+
+class LossDesc(C.Structure):
+    """Mirror of ``plc_loss_desc``."""
+    _fields_ = [
+        ("B", C.c_int), ("T", C.c_int), ("out_H", C.c_int), ("out_W", C.c_int), ("H", C.c_int), ("W", C.c_int),
+        ("N", C.c_int), ("values_per_batch", C.c_int), ("weight_mode", C.c_int),
+        ("scale_factor", C.c_float),
+        ("lambda_point", C.c_float), ("lambda_conserve", C.c_float), ("lambda_smooth", C.c_float),
+        ("lambda_temporal", C.c_float),
+        ("pred", _f), ("lr_input", _f), ("s_coords", _f), ("s_values", _f),
+        ("losses", _f), ("grad_pred", _f), ("workspace", _f), ("workspace_bytes", C.c_size_t),
     ]
 
 
@@ -104,6 +118,10 @@ def lib():
     L.plc_generator_bwd_workspace_bytes.argtypes = [C.POINTER(RolloutDesc)]
     L.plc_generator_rollout_bwd.restype = i
     L.plc_generator_rollout_bwd.argtypes = [C.POINTER(RolloutDesc), C.POINTER(RolloutGrads), p]
+    L.plc_combined_loss_workspace_bytes.restype = sz
+    L.plc_combined_loss_workspace_bytes.argtypes = [C.POINTER(LossDesc)]
+    L.plc_combined_loss.restype = i
+    L.plc_combined_loss.argtypes = [C.POINTER(LossDesc), p]
     _lib = L
     return L
 

@@ -557,3 +557,4 @@ extern "C" int plc_generator_rollout_fwd(const plc_rollout_desc* d, void* stream
 }
 
 #include "plc_bwd_api.h"
+#include "plc_loss_api.h"
