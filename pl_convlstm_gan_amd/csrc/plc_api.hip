@@ -145,16 +145,36 @@ static PlcTensor tens(const void* p, long long si, long long so) {
     return t;
 }
 
+// Number of CUs of the current device (an immutable device attribute, looked up once per device).
+static int cu_count() {
+    static int cached[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (cached[dev] == 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cached[dev] = n;
+    }
+    return cached[dev];
+}
+
 // One instantiation at a fixed tile height TH (and K split).
 template <int NCB0, int NCB1, int NMT, int KS, int STAGE, int EPI, int TH, int KSPLIT = 1>
 static int launch_conv_th(ConvArgs a, int n_img, int n_mgroups, hipStream_t st) {
-    constexpr int lds = plc_conv_lds_bytes<NCB0 + NCB1, KS, TH, KSPLIT>();
+    constexpr int lds = plc_conv_lds_bytes<NCB0 + NCB1, KS, TH, KSPLIT, STAGE>();
     auto kern = plc_conv_mfma_kernel<NCB0, NCB1, NMT, KS, STAGE, EPI, TH, KSPLIT>;
     if (lds > 65536)
         PLC_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     a.tiles_x = cdiv(a.W, 32);
     a.tiles_y = cdiv(a.H, TH);
-    hipLaunchKernelGGL(kern, dim3(n_img * a.tiles_x * a.tiles_y, n_mgroups), dim3(256), lds, st, a);
+    a.n_tiles = n_img * a.tiles_x * a.tiles_y;
+    // as many workgroups as stay resident (register- and LDS-limited), each walking an equal share of tiles
+    constexpr int by_waves = plc_conv_min_waves<NCB0 + NCB1, KS, KSPLIT, NMT, EPI>();
+    constexpr int by_lds = (160 * 1024) / lds;
+    const int resident = cu_count() * (by_waves < by_lds ? by_waves : by_lds) / n_mgroups;
+    const int per_wg = plc_conv_multi_tile<STAGE, EPI>() ? cdiv(a.n_tiles, resident > 0 ? resident : 1) : 1;
+    a.n_blocks = cdiv(a.n_tiles, per_wg);
+    hipLaunchKernelGGL(kern, dim3(a.n_blocks, n_mgroups), dim3(256), lds, st, a);
     PLC_HIP(hipGetLastError());
     return PLC_OK;
 }
@@ -163,7 +183,7 @@ static int launch_conv_th(ConvArgs a, int n_img, int n_mgroups, hipStream_t st) 
 template <int NCB0, int NCB1, int NMT, int KS, int STAGE, int EPI>
 static int launch_conv(ConvArgs a, int n_img, int n_mgroups, hipStream_t st) {
     const long long t16 = (long long)n_img * cdiv(a.H, 16) * cdiv(a.W, 32) * n_mgroups;
-    if (t16 >= 512) return launch_conv_th<NCB0, NCB1, NMT, KS, STAGE, EPI, 16>(a, n_img, n_mgroups, st);
+    if (t16 >= 512 && NMT != 1) return launch_conv_th<NCB0, NCB1, NMT, KS, STAGE, EPI, 16>(a, n_img, n_mgroups, st);
     return launch_conv_th<NCB0, NCB1, NMT, KS, STAGE, EPI, 8>(a, n_img, n_mgroups, st);
 }
 
@@ -179,9 +199,8 @@ static ConvArgs conv_args(int H, int W, int n_in) {
 // ---------------------------------------------------------------------------------------------
 // ConvLSTM cell
 // ---------------------------------------------------------------------------------------------
-static int cell_fwd_cb8(const void* x, const void* h, const float* c_in, const void* wpk, const float* bpk,
-                        void* h_out, float* c_out, void* gates, int B, int Cin, int Ch, int H, int W,
-                        hipStream_t st) {
+static ConvArgs cell_conv_args(const void* x, const void* h, const float* c_in, const void* wpk, const float* bpk,
+                               void* h_out, float* c_out, void* gates, int B, int Cin, int Ch, int H, int W) {
     const long long hw = (long long)H * W;
     ConvArgs a = conv_args(H, W, B);
     a.src0 = tens(x, (Cin / 8) * hw * 16, 0);
@@ -193,6 +212,13 @@ static int cell_fwd_cb8(const void* x, const void* h, const float* c_in, const v
     a.save_gates = gates != nullptr;
     a.wpk = (const uint4*)wpk;
     a.bpk = bpk;
+    return a;
+}
+
+static int cell_fwd_cb8(const void* x, const void* h, const float* c_in, const void* wpk, const float* bpk,
+                        void* h_out, float* c_out, void* gates, int B, int Cin, int Ch, int H, int W,
+                        hipStream_t st) {
+    const ConvArgs a = cell_conv_args(x, h, c_in, wpk, bpk, h_out, c_out, gates, B, Cin, Ch, H, W);
     if (Cin == 16 && Ch == 16)
         return gates ? launch_conv<2, 2, 2, 3, STAGE_CB8, EPI_LSTM_SAVE>(a, B, 1, st)
                      : launch_conv<2, 2, 2, 3, STAGE_CB8, EPI_LSTM>(a, B, 1, st);
@@ -487,18 +513,31 @@ extern "C" int plc_generator_rollout_fwd(const plc_rollout_desc* d, void* stream
     PLC_HIP(hipMemsetAsync(ws + p.c1s, 0, (size_t)B * p.img1 * 2, st));
     PLC_HIP(hipMemsetAsync(ws + p.h2s, 0, (size_t)B * p.img2, st));
     PLC_HIP(hipMemsetAsync(ws + p.c2s, 0, (size_t)B * p.img2 * 2, st));
-    for (int t = 0; t < T; ++t) {
+    {
         const size_t s1 = (size_t)B * p.img1, s2 = (size_t)B * p.img2;
-        char* g1 = d->save_for_backward ? ws + p.gates1 + (size_t)t * s1 * 4 : nullptr;
-        char* g2 = d->save_for_backward ? ws + p.gates2 + (size_t)t * s2 * 4 : nullptr;
-        if ((rc = cell_fwd_cb8(ws + p.xs + t * s1, ws + p.h1s + t * s1, (const float*)(ws + p.c1s + t * s1 * 2),
-                               ws + p.cell1.w, (const float*)(ws + p.cell1.b), ws + p.h1s + (t + 1) * s1,
-                               (float*)(ws + p.c1s + (t + 1) * s1 * 2), g1, B, C1, C1, H, W, st)))
-            return rc;
-        if ((rc = cell_fwd_cb8(ws + p.h1s + (t + 1) * s1, ws + p.h2s + t * s2, (const float*)(ws + p.c2s + t * s2 * 2),
-                               ws + p.cell2.w, (const float*)(ws + p.cell2.b), ws + p.h2s + (t + 1) * s2,
-                               (float*)(ws + p.c2s + (t + 1) * s2 * 2), g2, B, C1, C2, H, W, st)))
-            return rc;
+        const bool save = d->save_for_backward != 0;
+        auto cell1 = [&](int t) {
+            return cell_conv_args(ws + p.xs + t * s1, ws + p.h1s + t * s1, (const float*)(ws + p.c1s + t * s1 * 2),
+                                  ws + p.cell1.w, (const float*)(ws + p.cell1.b), ws + p.h1s + (t + 1) * s1,
+                                  (float*)(ws + p.c1s + (t + 1) * s1 * 2),
+                                  save ? ws + p.gates1 + (size_t)t * s1 * 4 : nullptr, B, C1, C1, H, W);
+        };
+        auto cell2 = [&](int t) {
+            return cell_conv_args(ws + p.h1s + (t + 1) * s1, ws + p.h2s + t * s2, (const float*)(ws + p.c2s + t * s2 * 2),
+                                  ws + p.cell2.w, (const float*)(ws + p.cell2.b), ws + p.h2s + (t + 1) * s2,
+                                  (float*)(ws + p.c2s + (t + 1) * s2 * 2),
+                                  save ? ws + p.gates2 + (size_t)t * s2 * 4 : nullptr, B, C1, C2, H, W);
+        };
+        // (Running cell 1 of step t+1 in the same launch as cell 2 of step t was measured: the two
+        // kinds of workgroup share each SIMD's matrix pipe and finish together, so nothing is gained.)
+        for (int t = 0; t < T; ++t) {
+            if ((rc = save ? launch_conv<2, 2, 2, 3, STAGE_CB8, EPI_LSTM_SAVE>(cell1(t), B, 1, st)
+                           : launch_conv<2, 2, 2, 3, STAGE_CB8, EPI_LSTM>(cell1(t), B, 1, st)))
+                return rc;
+            if ((rc = save ? launch_conv<2, 4, 4, 3, STAGE_CB8, EPI_LSTM_SAVE>(cell2(t), B, 1, st)
+                           : launch_conv<2, 4, 4, 3, STAGE_CB8, EPI_LSTM>(cell2(t), B, 1, st)))
+                return rc;
+        }
     }
 
     // ---- everything after the recurrence is batched over the T*B frames ----------------------
@@ -558,3 +597,15 @@ extern "C" int plc_generator_rollout_fwd(const plc_rollout_desc* d, void* stream
 
 #include "plc_bwd_api.h"
 #include "plc_loss_api.h"
+
+#ifdef PLC_TIMELINE
+// Instrumented build only: point the kernels' time-stamp buffer at `buf` (device memory, or null).
+extern "C" int plc_debug_set_timeline(void* buf) {
+    PLC_HIP(hipMemcpyToSymbol(HIP_SYMBOL(plc_timeline), &buf, sizeof(buf)));
+    return PLC_OK;
+}
+extern "C" int plc_debug_select_timeline(int id) {
+    PLC_HIP(hipMemcpyToSymbol(HIP_SYMBOL(plc_timeline_sel), &id, sizeof(id)));
+    return PLC_OK;
+}
+#endif

@@ -48,5 +48,5 @@ __device__ __forceinline__ float fast_sigmoid(float x) {
 }
 __device__ __forceinline__ float fast_tanh(float x) {
     // 1 - 2/(e^{2x}+1); saturates cleanly for |x| large (exp2 -> inf gives 1, -> 0 gives -1)
-    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.88539008177792681f * x));
+    return __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.88539008177792681f * x)), 1.0f);
 }

@@ -26,6 +26,31 @@
 
 #include "plc_common.h"
 
+#ifdef PLC_TIMELINE
+// Instrumented build only (never the shipped library): lane 0 of every wave records the 100 MHz
+// wall clock at phase boundaries into plc_timeline[(block * 4 + wave) * 8 + k].
+__device__ long long* plc_timeline = nullptr;
+__device__ int plc_timeline_sel = -1;   // only the instantiation with this id records (-1: all)
+#define PLC_TL_ID (NCB0 * 10000 + NCB1 * 1000 + STAGE * 100 + EPI * 10 + KSPLIT)
+#define PLC_STAMP(k)                                                                                   \
+    do {                                                                                               \
+        long long* tl_ = (plc_timeline_sel < 0 || plc_timeline_sel == PLC_TL_ID) ? plc_timeline : nullptr; \
+        if (tl_ && (threadIdx.x & 63) == 0)                                                            \
+            tl_[((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 10 + (k)] = (long long)wall_clock64(); \
+    } while (0)
+#define PLC_STAMP_HWID()                                                                               \
+    do {                                                                                               \
+        long long* tl_ = (plc_timeline_sel < 0 || plc_timeline_sel == PLC_TL_ID) ? plc_timeline : nullptr; \
+        if (tl_ && (threadIdx.x & 63) == 0) {                                                          \
+            tl_[((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 10 + 8] = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11));  \
+            tl_[((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 10 + 9] = __builtin_amdgcn_s_getreg((20) | (0 << 6) | (31 << 11)); \
+        }                                                                                              \
+    } while (0)
+#else
+#define PLC_STAMP(k) do {} while (0)
+#define PLC_STAMP_HWID() do {} while (0)
+#endif
+
 enum { STAGE_CB8 = 0, STAGE_CB8_GATED = 1, STAGE_COORD = 2, STAGE_F32_1CH = 3 };
 // EPI_LSTM_SAVE = EPI_LSTM that also stores the gate activations i,f,o,g for the backward pass
 enum { EPI_LSTM = 0, EPI_ACT_CB8 = 1, EPI_PIXSHUF_RELU = 2, EPI_F32_NCHW = 3, EPI_LSTM_SAVE = 4 };
@@ -35,6 +60,8 @@ enum { MUL_PRODUCT = 0, MUL_RELU_MASK = 1 };
 struct ConvArgs {
     int H, W;            // input == output spatial size (PixelShuffle epilogue writes 2H x 2W)
     int tiles_x, tiles_y;
+    int n_tiles;         // images * tiles_y * tiles_x
+    int n_blocks;        // workgroups per M group (gridDim.x); workgroup b takes tiles b, b + n_blocks, ...
     int n_in;            // inner image count for PlcTensor addressing
     int ncb_out;         // EPI_ACT_CB8: number of 8-channel blocks actually stored
     int cout;            // EPI_F32_NCHW: number of fp32 channels stored
@@ -109,7 +136,7 @@ __device__ __forceinline__ void plc_epilogue(const ConvArgs& a, const f32x16_t& 
             fg[j] = fast_sigmoid(acc[4 + j]);
             og[j] = fast_sigmoid(acc[8 + j]);
             gg[j] = fast_tanh(acc[12 + j]);
-            cn[j] = fg[j] * cpv[j] + ig[j] * gg[j];
+            cn[j] = __builtin_fmaf(fg[j], cpv[j], ig[j] * gg[j]);
             hn[j] = og[j] * fast_tanh(cn[j]);
         }
         *(float4*)(plc_img(a.out1, n, a.n_in) + coff) = make_float4(cn[0], cn[1], cn[2], cn[3]);
@@ -206,10 +233,12 @@ constexpr int plc_mfma_index(int f, int r, int KS, int NCBP, int NREP) {
 }
 
 // Dynamic LDS bytes of one instantiation.
-template <int NCB, int KS, int TH, int KSPLIT>
+template <int NCB, int KS, int TH, int KSPLIT, int STAGE = STAGE_CB8>
 constexpr int plc_conv_lds_bytes() {
-    // tile rounded up to whole 64-unit LDS-DMA pieces, the K-split exchange buffer, 32 units of bias
-    return ((NCB * (TH + 2 * (KS / 2)) * (32 + 2 * (KS / 2)) + 63) / 64 * 64 + (KSPLIT == 2 ? 4 * 4 * 64 : 0) + 32) * 16;
+    // tile rounded up to whole 64-unit LDS-DMA pieces (twice for the gated staging: the multiplier's
+    // tile lands next to it), the K-split exchange buffer, 32 units of bias
+    return ((NCB * (TH + 2 * (KS / 2)) * (32 + 2 * (KS / 2)) + 63) / 64 * 64 * (STAGE == STAGE_CB8_GATED ? 2 : 1) +
+            (KSPLIT == 2 ? 4 * 4 * 64 : 0) + 32) * 16;
 }
 
 // source of out-of-image units for the LDS-DMA staging
@@ -219,12 +248,26 @@ __device__ const uint4 plc_zero16 = {0u, 0u, 0u, 0u};
 // load/store latency rather than MFMA issue; two when the stationary weights need the registers.
 template <int NCB, int KS, int KSPLIT, int NMT, int EPI>
 constexpr int plc_conv_min_waves() {
-    return (NMT == 1 && EPI != EPI_LSTM && EPI != EPI_LSTM_SAVE && ((KS * KS * (NCB / KSPLIT) + 1) / 2) * 4 <= 80) ? 3 : 2;
+    constexpr int weight_vgprs = ((KS * KS * (NCB / KSPLIT) + 1) / 2) * 4;
+    // the fp32 NCHW epilogue needs its 64 accumulators live together with the store addresses
+    constexpr int limit = EPI == EPI_F32_NCHW ? 40 : 80;
+    return (NMT == 1 && EPI != EPI_LSTM && EPI != EPI_LSTM_SAVE && weight_vgprs <= limit) ? 3 : 2;
 }
 
+// Whether a workgroup of this instantiation walks several tiles.  The LSTM convs (register file and
+// scalar registers full) take exactly one tile per workgroup, and so do the convs that stage
+// through registers: they were measured to lose more from fewer workgroups in flight than they
+// gain from fetching their (few) weights once.
+template <int STAGE, int EPI>
+constexpr bool plc_conv_multi_tile() {
+    return EPI != EPI_LSTM && EPI != EPI_LSTM_SAVE && (STAGE == STAGE_CB8 || STAGE == STAGE_CB8_GATED);
+}
+
+// The work of one workgroup: tile `block_x` (image-major, then tile row, then tile column) of M
+// group `block_y` of `n_mgroups`; `tile` is the workgroup's dynamic LDS.
 template <int NCB0, int NCB1, int NMT, int KS, int STAGE, int EPI, int TH, int KSPLIT = 1>
-__global__ __launch_bounds__(256, (plc_conv_min_waves<NCB0 + NCB1, KS, KSPLIT, NMT, EPI>()))
-void plc_conv_mfma_kernel(const ConvArgs a) {
+__device__ __forceinline__ void plc_conv_body(const ConvArgs& a, const int block_x, const int block_y,
+                                              const int n_mgroups, uint4* const tile) {
     constexpr int NCB = NCB0 + NCB1;
     constexpr int NCBW = NCB / KSPLIT;       // channel blocks contracted by one wave
     constexpr int TAPS = KS * KS;
@@ -249,10 +292,11 @@ void plc_conv_mfma_kernel(const ConvArgs a) {
     constexpr int RED_UNITS = KSPLIT == 2 ? 4 * 4 * 64 : 0;   // partial-sum exchange, 16 B units
     constexpr int TILE_UNITS = (NCB * PLANE + 63) / 64 * 64;   // whole 64-unit DMA pieces
     constexpr int BIAS_UNITS = 32;                             // 4 M tiles x 32 rows of fp32 bias
-    static_assert((TILE_UNITS + RED_UNITS + BIAS_UNITS) * 16 <= 160 * 1024, "LDS tile too large");
-    static_assert((TILE_UNITS + RED_UNITS + BIAS_UNITS) * 16 == plc_conv_lds_bytes<NCB, KS, TH, KSPLIT>(), "LDS size mismatch");
-
-    extern __shared__ __attribute__((aligned(16))) uint4 tile[];   // TILE_UNITS + RED_UNITS units
+    constexpr int GATE_UNITS = STAGE == STAGE_CB8_GATED ? TILE_UNITS : 0;   // multiplier tile, after the bias
+    static_assert((TILE_UNITS + RED_UNITS + BIAS_UNITS + GATE_UNITS) * 16 <= 160 * 1024, "LDS tile too large");
+    static_assert((TILE_UNITS + RED_UNITS + BIAS_UNITS + GATE_UNITS) * 16 == plc_conv_lds_bytes<NCB, KS, TH, KSPLIT, STAGE>(),
+                  "LDS size mismatch");
+    static_assert(STAGE != STAGE_CB8_GATED || NCB1 == 0, "the gated staging takes one source");
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -262,34 +306,66 @@ void plc_conv_mfma_kernel(const ConvArgs a) {
     const int m = wave % NMT;
     const int ks = (wave / NMT) % KSPLIT;
     const int rg = wave / (NMT * KSPLIT);
-    const int mt = blockIdx.y * NMT + m;     // global M tile index
-    const int n_mt = gridDim.y * NMT;
+    const int mt = block_y * NMT + m;        // global M tile index
+    const int n_mt = n_mgroups * NMT;
 
-    int bid = blockIdx.x;
-    const int tx = bid % a.tiles_x;
-    bid /= a.tiles_x;
-    const int ty = bid % a.tiles_y;
-    const int n = bid / a.tiles_y;
-    const int x0 = tx * 32, y0 = ty * TH;
     const int H = a.H, W = a.W;
 
-    // ---- weights: stationary A fragments -------------------------------------------------
+    PLC_STAMP(0);
+    PLC_STAMP_HWID();
+    // ---- weights: stationary A fragments, fetched once per workgroup ------------------------
     bf16x8_t wf[NKS];
     {
         const uint4* wp = a.wpk + ((long long)(mt * KSPLIT + ks) * NKS) * 64 + lane;
 #pragma unroll
         for (int s = 0; s < NKS; ++s) wf[s] = __builtin_bit_cast(bf16x8_t, wp[s * 64]);
     }
+    // this workgroup's bias rows (row order of the packed M tiles) for the pipelined LSTM path
+    if (tid < NMT * 32) ((float*)(tile + TILE_UNITS + RED_UNITS))[tid] = a.bpk[block_y * NMT * 32 + tid];
 
+    constexpr bool IS_LSTM = (EPI == EPI_LSTM || EPI == EPI_LSTM_SAVE);
+    constexpr bool PIPE = IS_LSTM && KSPLIT == 1 && (NCBW % 2 == 0);
+    float4 bv[4];   // bias of this lane's 16 rows (accumulator initial value of the generic pass loop)
+    auto load_bias = [&]() {
+        const float4* bias4 = (const float4*)a.bpk + mt * 8;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            // the K-split instantiations are the bias-free data-gradient convs
+            bv[g] = KSPLIT == 2 ? make_float4(0.f, 0.f, 0.f, 0.f) : bias4[2 * g + half];
+        }
+        // retire these loads here: a load still pending at the loop head would make the compiler
+        // wait vmcnt(0) before the first MFMA of every pass, i.e. also for the prefetch issued there
+#pragma unroll
+        for (int g = 0; g < 4; ++g) asm volatile("" : "+v"(bv[g].x), "+v"(bv[g].y), "+v"(bv[g].z), "+v"(bv[g].w));
+    };
+    if constexpr (!PIPE) load_bias();   // the pipelined LSTM path takes its bias from LDS instead
+
+    // ---- the workgroup's tiles: block_x, block_x + n_blocks, ... ----------------------------
+    // A launch holds at most as many workgroups as the chip keeps resident; with more tiles than
+    // that each workgroup walks several, so the weights (whose re-fetch from L2 would otherwise
+    // exceed the activation traffic of the light convs) cross the fabric once per workgroup.
+#pragma unroll 1
+    for (int tile_id = block_x; tile_id < a.n_tiles; tile_id += a.n_blocks) {
+    if (tile_id != block_x) __syncthreads();   // every wave is done reading the previous tile
+    int bid = tile_id;
+    const int tx = bid % a.tiles_x;
+    bid /= a.tiles_x;
+    const int ty = bid % a.tiles_y;
+    const int n = bid / a.tiles_y;
+    const int x0 = tx * 32, y0 = ty * TH;
+
+    PLC_STAMP(1);
     // ---- stage the input halo tile into LDS ----------------------------------------------
     {
         const char* s0 = plc_img(a.src0, n, a.n_in);
         const char* s1 = NCB1 > 0 ? plc_img(a.src1, n, a.n_in) : nullptr;
         const char* gt = STAGE == STAGE_CB8_GATED ? plc_img(a.gate, n, a.n_in) : nullptr;
-        if constexpr (STAGE == STAGE_CB8) {
+        if constexpr (STAGE == STAGE_CB8 || STAGE == STAGE_CB8_GATED) {
             // LDS-DMA: each wave instruction moves 64 consecutive units (1 KiB) straight from
             // global memory into the tile, no VGPRs and no ds_write; out-of-image units read a
             // 16-byte block of zeros instead.  All of a wave's pieces are in flight together.
+            // Gated staging: the multiplier's tile is fetched the same way into a second region
+            // and the product (rounded to bf16 once) replaces the tile in a pass over LDS.
             constexpr int NCHUNK = TILE_UNITS / 64;
             const long long plane_b = (long long)H * W * 16;
             const int wave_u = __builtin_amdgcn_readfirstlane(wave);
@@ -302,11 +378,31 @@ void plc_conv_mfma_kernel(const ConvArgs a) {
                 const int gy = y0 - PAD + ly, gx = x0 - PAD + lx;
                 const bool ok = (cb < NCB) & (gy >= 0) & (gy < H) & (gx >= 0) & (gx < W);
                 const char* base = (cb < NCB0) ? (s0 + cb * plane_b) : (s1 + (cb - NCB0) * plane_b);
+                const long long poff = cb * plane_b + ((long long)gy * W + gx) * 16;
                 const char* src = ok ? base + ((long long)gy * W + gx) * 16 : (const char*)&plc_zero16;
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                                  (__attribute__((address_space(3))) void*)(tile + ch * 64), 16, 0, 0);
+                if constexpr (STAGE == STAGE_CB8_GATED) {
+                    const char* gsrc = ok ? gt + poff : (const char*)&plc_zero16;
+                    __builtin_amdgcn_global_load_lds(
+                        (const __attribute__((address_space(1))) void*)gsrc,
+                        (__attribute__((address_space(3))) void*)(tile + TILE_UNITS + RED_UNITS + BIAS_UNITS + ch * 64), 16, 0, 0);
+                }
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if constexpr (STAGE == STAGE_CB8_GATED) {
+                // a wave multiplies the pieces it fetched itself, so no barrier is needed in between
+                const uint4* gtile = tile + TILE_UNITS + RED_UNITS + BIAS_UNITS;
+                for (int ch = wave_u; ch < NCHUNK; ch += 4) {
+                    const int u = ch * 64 + lane;
+                    const uint4 f = tile[u], g = gtile[u];
+                    const float4 f0 = unpack_bf4(make_uint2(f.x, f.y)), f1 = unpack_bf4(make_uint2(f.z, f.w));
+                    const float4 g0 = unpack_bf4(make_uint2(g.x, g.y)), g1 = unpack_bf4(make_uint2(g.z, g.w));
+                    const uint2 lo = pack_bf4(f0.x * g0.x, f0.y * g0.y, f0.z * g0.z, f0.w * g0.w);
+                    const uint2 hi = pack_bf4(f1.x * g1.x, f1.y * g1.y, f1.z * g1.z, f1.w * g1.w);
+                    tile[u] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+                }
+            }
         } else {
             // register staging (the unit needs arithmetic): four independent units in flight
             constexpr int NIT = (NCB * PLANE + 255) / 256;
@@ -331,13 +427,11 @@ void plc_conv_mfma_kernel(const ConvArgs a) {
             }
         }
     }
-    // this workgroup's bias rows (row order of the packed M tiles) for the pipelined LSTM path
-    if (tid < NMT * 32) ((float*)(tile + TILE_UNITS + RED_UNITS))[tid] = a.bpk[blockIdx.y * NMT * 32 + tid];
+    PLC_STAMP(2);
     __syncthreads();
+    PLC_STAMP(3);
 
     const char* lds = (const char*)tile;
-    constexpr bool IS_LSTM = (EPI == EPI_LSTM || EPI == EPI_LSTM_SAVE);
-    constexpr bool PIPE = IS_LSTM && KSPLIT == 1 && (NCBW % 2 == 0);
     if constexpr (PIPE) {
         if (y0 + TH <= H && x0 + 32 <= W) {
             // Whole tile inside the image: branch-free, and the epilogue of pass p-1 (sigma/tanh/
@@ -427,18 +521,20 @@ void plc_conv_mfma_kernel(const ConvArgs a) {
                             ti = rr;
                             rec(R{}, std::integral_constant<int, 0>{}, J{}, ti);
                         } else if constexpr (act == 1) {
-                            const float g = 1.0f - 2.0f * rr;
+                            // explicit fma: every instantiation must round identically (a batch of 4
+                            // and four batches of 1 take different tile heights and must agree bitwise)
+                            const float g = __builtin_fmaf(-2.0f, rr, 1.0f);
                             tig = ti * g;
                             rec(R{}, std::integral_constant<int, 3>{}, J{}, g);
                         } else if constexpr (act == 2) {
                             const float cj = j == 0 ? cold[r].x : j == 1 ? cold[r].y : j == 2 ? cold[r].z : cold[r].w;
-                            cn[j] = rr * cj + tig;
+                            cn[j] = __builtin_fmaf(rr, cj, tig);
                             rec(R{}, std::integral_constant<int, 1>{}, J{}, rr);
                         } else if constexpr (act == 3) {
                             to = rr;
                             rec(R{}, std::integral_constant<int, 2>{}, J{}, to);
                         } else {
-                            const float h = to * (1.0f - 2.0f * rr);
+                            const float h = to * __builtin_fmaf(-2.0f, rr, 1.0f);
                             if constexpr (j & 1) hp[j >> 1] = pack_bf2(he, h);
                             else he = h;
                         }
@@ -496,31 +592,27 @@ void plc_conv_mfma_kernel(const ConvArgs a) {
             init_acc(accA);
             init_acc(accB);
             run(std::true_type{}, std::false_type{}, accA, cA, accB, cB, 0);
+            PLC_STAMP(4);
 #pragma unroll 1
             for (int pass = 1; pass < PASSES; pass += 2) {
                 run(std::true_type{}, std::true_type{}, accB, cB, accA, cA, pass);
                 if (pass + 1 < PASSES) run(std::true_type{}, std::true_type{}, accA, cA, accB, cB, pass + 1);
             }
+            PLC_STAMP(5);
             if constexpr (PASSES % 2 == 0) run(std::false_type{}, std::true_type{}, accA, cA, accB, cB, PASSES);
             else run(std::false_type{}, std::true_type{}, accB, cB, accA, cA, PASSES);
-            return;
+            PLC_STAMP(6);
+#ifdef PLC_TIMELINE
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            PLC_STAMP(7);
+#endif
+            return;   // (the LSTM convs take one tile per workgroup)
         }
     }
 
-    float4 bv[4];   // bias of this lane's 16 rows (accumulator initial value)
-    {
-        const float4* bias4 = (const float4*)a.bpk + mt * 8;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            // the K-split instantiations are the bias-free data-gradient convs
-            bv[g] = KSPLIT == 2 ? make_float4(0.f, 0.f, 0.f, 0.f) : bias4[2 * g + half];
-        }
-        // retire these loads here: a load still pending at the loop head would make the compiler
-        // wait vmcnt(0) before the first MFMA of every pass, i.e. also for the prefetch issued there
-#pragma unroll
-        for (int g = 0; g < 4; ++g) asm volatile("" : "+v"(bv[g].x), "+v"(bv[g].y), "+v"(bv[g].z), "+v"(bv[g].w));
-    }
+    if constexpr (PIPE) load_bias();   // (only partly filled tiles of the LSTM convs get here)
 
+    PLC_STAMP(4);
 #pragma unroll 1
     for (int pass = 0; pass < PASSES; ++pass) {
         const int row0 = rg * RPW + pass * NREP;
@@ -647,4 +739,19 @@ void plc_conv_mfma_kernel(const ConvArgs a) {
             }
         }
     }
+    PLC_STAMP(6);
+#ifdef PLC_TIMELINE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    PLC_STAMP(7);
+#endif
+    if constexpr (!plc_conv_multi_tile<STAGE, EPI>()) break;
+    }   // tile loop
 }
+
+template <int NCB0, int NCB1, int NMT, int KS, int STAGE, int EPI, int TH, int KSPLIT = 1>
+__global__ __launch_bounds__(256, (plc_conv_min_waves<NCB0 + NCB1, KS, KSPLIT, NMT, EPI>()))
+void plc_conv_mfma_kernel(const ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint4 plc_conv_tile[];
+    plc_conv_body<NCB0, NCB1, NMT, KS, STAGE, EPI, TH, KSPLIT>(a, blockIdx.x, blockIdx.y, gridDim.y, plc_conv_tile);
+}
+

@@ -79,7 +79,7 @@ extern "C" int plc_combined_loss(const plc_loss_desc* d, void* stream) {
     if (p.vec == 4) hipLaunchKernelGGL(plc_loss_main_kernel<4>, dim3(p.n_main), dim3(256), 0, st, a);
     else hipLaunchKernelGGL(plc_loss_main_kernel<1>, dim3(p.n_main), dim3(256), 0, st, a);
     PLC_HIP(hipGetLastError());
-    hipLaunchKernelGGL(plc_loss_finalize_kernel, dim3(1), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(plc_loss_finalize_kernel, dim3(1), dim3(LOSS_FIN_THREADS), 0, st, a);
     PLC_HIP(hipGetLastError());
     return PLC_OK;
 }

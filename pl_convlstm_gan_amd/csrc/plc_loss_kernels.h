@@ -45,12 +45,15 @@ __device__ __forceinline__ float plc_wave_sum(float v) {
     return v;
 }
 
-// Sum of `v` over the 256 threads of a block; valid in thread 0.  `red` holds 4 floats per value.
+// Sum of `v` over the NW waves of a block, the same value in every thread.  `red` holds NW floats.
+template <int NW = 4>
 __device__ __forceinline__ float plc_block_sum(float v, float* red) {
     v = plc_wave_sum(v);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
     __syncthreads();
-    const float s = red[0] + red[1] + red[2] + red[3];
+    float s = 0.0f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) s += red[w];
     __syncthreads();
     return s;
 }
@@ -211,36 +214,37 @@ __device__ __forceinline__ bool plc_gauge_pixel(const LossArgs& a, int n, int& r
 
 // Pixel offset of station n inside a frame, or -1 when it falls outside the prediction grid.
 constexpr int LOSS_PIX_CACHE = 2048;
+constexpr int LOSS_FIN_THREADS = 1024;   // one block; its work is a chain of dependent loads per element
 __device__ __forceinline__ int plc_gauge_offset(const LossArgs& a, const int* cache, int n) {
     if (n < LOSS_PIX_CACHE) return cache[n];
     int r, c;
     return plc_gauge_pixel(a, n, r, c) ? r * a.Wh + c : -1;
 }
 
-__global__ __launch_bounds__(256) void plc_loss_finalize_kernel(const LossArgs a) {
-    __shared__ float red[4];
+__global__ __launch_bounds__(LOSS_FIN_THREADS) void plc_loss_finalize_kernel(const LossArgs a) {
+    __shared__ float red[LOSS_FIN_THREADS / 64];
     __shared__ float sh_k;
     __shared__ int pix[LOSS_PIX_CACHE];
     const int tid = threadIdx.x;
-    for (int n = tid; n < a.N && n < LOSS_PIX_CACHE; n += 256) {
+    for (int n = tid; n < a.N && n < LOSS_PIX_CACHE; n += LOSS_FIN_THREADS) {
         int r, c;
         pix[n] = plc_gauge_pixel(a, n, r, c) ? r * a.Wh + c : -1;
     }
     // fixed-order sums of the block partials
     float s[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int b = tid; b < a.n_main_blocks; b += 256) {
+    for (int b = tid; b < a.n_main_blocks; b += LOSS_FIN_THREADS) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) s[k] += a.partials[(long long)b * 4 + k];
     }
-    for (int b = tid; b < a.n_pool_blocks; b += 256) s[3] += a.partials[(long long)a.n_main_blocks * 4 + b];
-    const float Sx = plc_block_sum(s[0], red), Sy = plc_block_sum(s[1], red);
-    const float St = plc_block_sum(s[2], red), Sc = plc_block_sum(s[3], red);   // (also orders pix[] writes)
+    for (int b = tid; b < a.n_pool_blocks; b += LOSS_FIN_THREADS) s[3] += a.partials[(long long)a.n_main_blocks * 4 + b];
+    const float Sx = plc_block_sum<LOSS_FIN_THREADS / 64>(s[0], red), Sy = plc_block_sum<LOSS_FIN_THREADS / 64>(s[1], red);
+    const float St = plc_block_sum<LOSS_FIN_THREADS / 64>(s[2], red), Sc = plc_block_sum<LOSS_FIN_THREADS / 64>(s[3], red);   // (also orders pix[] writes)
 
     // rain-gauge term: one (frame, station) element per thread and iteration
     const long long plane = (long long)a.Hh * a.Wh;
     const long long items = (long long)a.B * a.T * a.N;
     float psum = 0.0f, pcnt = 0.0f;
-    for (long long it = tid; it < items; it += 256) {
+    for (long long it = tid; it < items; it += LOSS_FIN_THREADS) {
         const int n = (int)(it % a.N);
         const int f = (int)(it / a.N);
         const int o = plc_gauge_offset(a, pix, n);
@@ -251,7 +255,7 @@ __global__ __launch_bounds__(256) void plc_loss_finalize_kernel(const LossArgs a
         psum += fabsf(a.pred[(long long)f * plane + o] - obs) * plc_gauge_weight(obs, a.weight_mode);
         pcnt += 1.0f;
     }
-    const float Ps = plc_block_sum(psum, red), Pc = plc_block_sum(pcnt, red);
+    const float Ps = plc_block_sum<LOSS_FIN_THREADS / 64>(psum, red), Pc = plc_block_sum<LOSS_FIN_THREADS / 64>(pcnt, red);
     if (tid == 0) {
         const float fB = (float)a.B, fT = (float)a.T, fH = (float)a.Hh, fW = (float)a.Wh;
         const float point = Pc > 0.0f ? Ps / Pc : 0.0f;
@@ -268,7 +272,7 @@ __global__ __launch_bounds__(256) void plc_loss_finalize_kernel(const LossArgs a
     // Gradient of the gauge term.  Stations sharing a pixel are added by the first of them, in
     // station order, so the result does not depend on thread scheduling.
     const float k = sh_k;
-    for (long long it = tid; it < items; it += 256) {
+    for (long long it = tid; it < items; it += LOSS_FIN_THREADS) {
         const int n = (int)(it % a.N);
         const int f = (int)(it / a.N);
         const int o = plc_gauge_offset(a, pix, n);
