@@ -158,7 +158,8 @@ def main():
     with torch.no_grad():
         model(rain[:1, :1].contiguous(), dem[:1].contiguous(), lu[:1].contiguous())   # materialise lazy blocks
     loss_module = CombinedLoss()
-    opt = torch.optim.Adam(model.parameters(), lr=5e-4)
+    from pl_convlstm_gan_amd.optim import FusedAdam
+    opt = FusedAdam(model.parameters(), lr=5e-4)   # torch.optim.Adam's rule; clip + step in two launches
     dbg("model and data ready")
 
     def step_train():

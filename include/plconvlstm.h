@@ -217,6 +217,35 @@ typedef struct plc_loss_desc {
 size_t plc_combined_loss_workspace_bytes(const plc_loss_desc* d);
 int plc_combined_loss(const plc_loss_desc* d, void* stream);
 
+/* ---------------------------------------------------------------------------------------
+ * Gradient clipping + Adam.  Replaces torch.nn.utils.clip_grad_norm_(model.parameters(),
+ * max_norm) followed by torch.optim.Adam.step() in the reference's training step
+ * (src/training/trainer.py:311-313; Adam with the reference's settings: lr from the config, default
+ * betas / eps, weight_decay = 0, no amsgrad):
+ *   norm = sqrt(sum over all listed gradients of g^2);  clip = min(1, max_norm / (norm + 1e-6))
+ *   g *= clip (in place, every listed tensor)
+ *   for tensors with update != 0:  g += weight_decay * p;  m += (1 - beta1)(g - m);
+ *       v = beta2 v + (1 - beta2) g^2;  p -= lr / (1 - beta1^step) * m / (sqrt(v) / sqrt(1 - beta2^step) + eps)
+ * Tensors with update == 0 count in the norm and are clipped but not stepped (the reference's
+ * optimizer does not hold the generator's lazily created upsample blocks, yet its clip covers
+ * them).  `step` is the 1-based number of this update.  The table `t` is read on the host during
+ * the call; `grad_norm` (device, 1 float, may be NULL) receives the norm before clipping.
+ * max_norm <= 0 disables clipping.  Two launches, no host synchronisation.
+ * ------------------------------------------------------------------------------------- */
+typedef struct plc_opt_tensor {
+    float* param;        /* may be NULL when update == 0 */
+    float* grad;
+    float* exp_avg;      /* Adam first moment  (may be NULL when update == 0) */
+    float* exp_avg_sq;   /* Adam second moment (may be NULL when update == 0) */
+    long long numel;
+    int update;
+} plc_opt_tensor;
+
+size_t plc_clip_adam_workspace_bytes(const plc_opt_tensor* t, int n);
+int plc_clip_adam_step(const plc_opt_tensor* t, int n, double max_norm, double lr, double beta1, double beta2,
+                       double eps, double weight_decay, long long step, float* grad_norm,
+                       void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -20,6 +20,7 @@ EXPORTS = (
     "plc_convlstm_cell_bwd_workspace_bytes", "plc_convlstm_cell_bwd",
     "plc_generator_bwd_workspace_bytes", "plc_generator_rollout_bwd",
     "plc_combined_loss_workspace_bytes", "plc_combined_loss",
+    "plc_clip_adam_workspace_bytes", "plc_clip_adam_step",
 )
 
 _f = C.c_void_p   # device pointers travel as plain addresses
@@ -69,6 +70,12 @@ class LossDesc(C.Structure):
         ("pred", _f), ("lr_input", _f), ("s_coords", _f), ("s_values", _f),
         ("losses", _f), ("grad_pred", _f), ("workspace", _f), ("workspace_bytes", C.c_size_t),
     ]
+
+
+class OptTensor(C.Structure):
+    """Mirror of ``plc_opt_tensor``."""
+    _fields_ = [("param", _f), ("grad", _f), ("exp_avg", _f), ("exp_avg_sq", _f),
+                ("numel", C.c_longlong), ("update", C.c_int)]
 
 
 _lib = None
@@ -122,6 +129,11 @@ def lib():
     L.plc_combined_loss_workspace_bytes.argtypes = [C.POINTER(LossDesc)]
     L.plc_combined_loss.restype = i
     L.plc_combined_loss.argtypes = [C.POINTER(LossDesc), p]
+    L.plc_clip_adam_workspace_bytes.restype = sz
+    L.plc_clip_adam_workspace_bytes.argtypes = [C.POINTER(OptTensor), i]
+    L.plc_clip_adam_step.restype = i
+    L.plc_clip_adam_step.argtypes = [C.POINTER(OptTensor), i, C.c_double, C.c_double, C.c_double, C.c_double,
+                                     C.c_double, C.c_double, C.c_longlong, p, p, sz, p]
     _lib = L
     return L
 

@@ -597,6 +597,7 @@ extern "C" int plc_generator_rollout_fwd(const plc_rollout_desc* d, void* stream
 
 #include "plc_bwd_api.h"
 #include "plc_loss_api.h"
+#include "plc_opt_api.h"
 
 #ifdef PLC_TIMELINE
 // Instrumented build only: point the kernels' time-stamp buffer at `buf` (device memory, or null).

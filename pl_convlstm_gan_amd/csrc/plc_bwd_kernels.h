@@ -48,7 +48,7 @@ struct LstmBwdArgs {
     const char* dc_in;             // fp32 CB8 [B][ncb] or null
     const char* gates;             // bf16 CB8 [B][4*ncb]
     const char* c_prev;            // fp32 CB8 [B][ncb]
-    const char* c_cur;             // fp32 CB8 [B][ncb]
+    const char* c_cur;             // fp32 CB8 [B][ncb] (not read: c_t is rebuilt from gates and c_prev)
     char* dz;                      // bf16 CB8 [B][4*ncb]
     char* dc_out;                  // fp32 CB8 [B][ncb]
 };
@@ -81,13 +81,16 @@ __global__ void plc_lstm_pointwise_bwd_kernel(const LstmBwdArgs a) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) dcin.v[j] = 0.0f;
         }
-        const F8 cp = ld_f8(a.c_prev + su * 32), cc = ld_f8(a.c_cur + su * 32);
+        const F8 cp = ld_f8(a.c_prev + su * 32);
         const F8 gi = ld_bf8(a.gates + (gu + 0 * a.ncb * hw) * 16), gf = ld_bf8(a.gates + (gu + 1 * a.ncb * hw) * 16);
         const F8 go = ld_bf8(a.gates + (gu + 2 * a.ncb * hw) * 16), gg = ld_bf8(a.gates + (gu + 3 * a.ncb * hw) * 16);
         F8 zi, zf, zo, zg, dcp;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const float tc = fast_tanh(cc.v[j]);
+            // c_t is rebuilt from the saved gates and c_{t-1} (one fma) instead of being read back:
+            // 32 of the 288 bytes a unit moves; the saved gates are bf16, so c_t differs from the
+            // forward's by their rounding, well inside the gradient tolerance
+            const float tc = fast_tanh(__builtin_fmaf(gf.v[j], cp.v[j], gi.v[j] * gg.v[j]));
             const float d_o = dh.v[j] * tc;
             const float dct = dcin.v[j] + dh.v[j] * go.v[j] * (1.0f - tc * tc);
             zi.v[j] = dct * gg.v[j] * gi.v[j] * (1.0f - gi.v[j]);

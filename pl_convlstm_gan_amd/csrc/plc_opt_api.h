@@ -1,0 +1,85 @@
+// C ABI of the fused gradient clip + Adam step (included at the end of plc_api.hip).
+#pragma once
+#include <math.h>
+
+#include "plc_opt_kernels.h"
+
+static long long opt_chunk_elems(const plc_opt_tensor* t, int first, int n) {
+    long long s = 0;
+    for (int k = first; k < first + n; ++k) s += t[k].numel;
+    return s;
+}
+
+static int opt_blocks(long long elems) { return (int)((elems + OPT_ELEMS_PER_BLOCK - 1) / OPT_ELEMS_PER_BLOCK); }
+
+extern "C" size_t plc_clip_adam_workspace_bytes(const plc_opt_tensor* t, int n) {
+    if (!t || n <= 0) return 0;
+    long long blocks = 0;
+    for (int first = 0; first < n; first += OPT_MAX_TENSORS) {
+        const int cnt = n - first < OPT_MAX_TENSORS ? n - first : OPT_MAX_TENSORS;
+        blocks += opt_blocks(opt_chunk_elems(t, first, cnt));
+    }
+    return align256((size_t)blocks * sizeof(float));
+}
+
+extern "C" int plc_clip_adam_step(const plc_opt_tensor* t, int n, double max_norm, double lr, double beta1,
+                                  double beta2, double eps, double weight_decay, long long step, float* grad_norm,
+                                  void* workspace, size_t workspace_bytes, void* stream) {
+    PLC_REQUIRE(t && n > 0, "plc_clip_adam_step: empty tensor table");
+    PLC_REQUIRE(step >= 1, "plc_clip_adam_step: step must be >= 1 (the number of this update)");
+    PLC_REQUIRE(lr >= 0.0 && beta1 >= 0.0 && beta1 < 1.0 && beta2 >= 0.0 && beta2 < 1.0 && eps >= 0.0,
+                "plc_clip_adam_step: bad hyper-parameter");
+    for (int k = 0; k < n; ++k) {
+        PLC_REQUIRE(t[k].numel > 0 && t[k].grad, "plc_clip_adam_step: tensor %d has no gradient or no elements", k);
+        PLC_REQUIRE(!t[k].update || (t[k].param && t[k].exp_avg && t[k].exp_avg_sq),
+                    "plc_clip_adam_step: tensor %d is to be updated but lacks param / exp_avg / exp_avg_sq", k);
+    }
+    const size_t need = plc_clip_adam_workspace_bytes(t, n);
+    PLC_REQUIRE(workspace, "plc_clip_adam_step: null workspace");
+    if (workspace_bytes < need)
+        return plc_fail(PLC_EWORKSPACE, "plc_clip_adam_step: workspace %zu < %zu bytes", workspace_bytes, need);
+    hipStream_t st = (hipStream_t)stream;
+    float* partials = (float*)workspace;
+
+    AdamScalars sc;
+    // every derived scalar is formed in double, as the Python optimizer does, and rounded once
+    sc.max_norm = (float)max_norm;
+    sc.beta1 = (float)beta1;
+    sc.beta2 = (float)beta2;
+    sc.omb1 = (float)(1.0 - beta1);
+    sc.omb2 = (float)(1.0 - beta2);
+    sc.eps = (float)eps;
+    sc.weight_decay = (float)weight_decay;
+    sc.step_size = (float)(lr / (1.0 - pow(beta1, (double)step)));
+    sc.bc2_sqrt = (float)sqrt(1.0 - pow(beta2, (double)step));
+
+    int n_partials = 0;
+    for (int pass = 0; pass < 2; ++pass) {
+        int part_off = 0;
+        for (int first = 0; first < n; first += OPT_MAX_TENSORS) {
+            const int cnt = n - first < OPT_MAX_TENSORS ? n - first : OPT_MAX_TENSORS;
+            OptTable tb;
+            memset(&tb, 0, sizeof(tb));
+            tb.n = cnt;
+            long long off = 0;
+            for (int k = 0; k < cnt; ++k) {
+                const plc_opt_tensor& s = t[first + k];
+                tb.param[k] = s.param; tb.grad[k] = s.grad; tb.exp_avg[k] = s.exp_avg; tb.exp_avg_sq[k] = s.exp_avg_sq;
+                tb.update[k] = s.update;
+                tb.start[k] = off;
+                off += s.numel;
+            }
+            tb.start[cnt] = off;
+            const int blocks = opt_blocks(off);
+            if (pass == 0)
+                hipLaunchKernelGGL(plc_grad_sqnorm_kernel, dim3(blocks), dim3(256), 0, st, tb, partials + part_off);
+            else
+                hipLaunchKernelGGL(plc_clip_adam_kernel, dim3(blocks), dim3(256), 0, st, tb, (const float*)partials,
+                                   n_partials, sc, first == 0 ? grad_norm : (float*)nullptr);
+            PLC_HIP(hipGetLastError());
+            part_off += blocks;
+        }
+        n_partials = part_off;
+    }
+    return PLC_OK;
+}

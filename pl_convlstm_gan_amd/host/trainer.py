@@ -89,7 +89,9 @@ class Trainer:
             torch.manual_seed(0)      # identical initial weights on every rank
         self.model = Generator(**kw).to(self.device)
         tr = self.config.training
-        self.optimizer = torch.optim.Adam(self.model.parameters(), lr=tr.learning_rate)
+        # Adam as the reference (trainer.py:153-158); FusedAdam keeps torch.optim.Adam's state_dict layout
+        from ..optim import FusedAdam
+        self.optimizer = FusedAdam(self.model.parameters(), lr=tr.learning_rate)
         self.scheduler = torch.optim.lr_scheduler.ReduceLROnPlateau(self.optimizer, mode="min", factor=tr.scheduler_factor,
                                                                     patience=tr.scheduler_patience)
         self.loss_module = CombinedLoss(lambda_point=tr.lambda_point, lambda_conserve=tr.lambda_conserve,

@@ -76,10 +76,17 @@ def train_step(model, loss_module, optimizer, rain_lr, dem, lu, s_coords, s_valu
     if any_rank_true(torch.isnan(loss.detach()), group):
         return loss, loss_dict, fake_hr, True
     loss.backward()
-    bucket = GradBucket(clip_params if clip_params is not None else model.parameters())
-    flat = bucket.gather()
-    all_reduce_mean_(flat, group)
-    clip_flat_(flat, max_norm)
-    bucket.scatter()
-    optimizer.step()
+    params = list(clip_params if clip_params is not None else model.parameters())
+    fused = hasattr(optimizer, "clip_and_step")     # optim.FusedAdam: clip + Adam in two launches
+    if _world(group) > 1 or not fused:
+        bucket = GradBucket(params)
+        flat = bucket.gather()
+        all_reduce_mean_(flat, group)
+        if not fused:
+            clip_flat_(flat, max_norm)
+        bucket.scatter()
+    if fused:
+        optimizer.clip_and_step(params, max_norm)
+    else:
+        optimizer.step()
     return loss, loss_dict, fake_hr, False
