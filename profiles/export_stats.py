@@ -1,5 +1,6 @@
 """Export the per-kernel summary of a rocprofv3 --kernel-trace --stats run (its rocpd SQLite
-database) as CSV:  python profiles/export_stats.py <results.db> <out.csv>"""
+database) as CSV:  python profiles/export_stats.py <results.db> <out.csv>
+The view's durations are microseconds."""
 import csv
 import sqlite3
 import sys
@@ -14,6 +15,7 @@ with open(sys.argv[2], "w", newline="") as fh:
     w.writerows(rows)
 total = sum(r[2] for r in rows)
 lib = sum(r[2] for r in rows if "plc_" in r[0])
-print(f"{len(rows)} kernels, total {total / 1e3:.1f} us, libplconvlstm {lib / 1e3:.1f} us")
+print(f"{len(rows)} kernels, total {total / 1e3:.2f} ms, libplconvlstm {lib / 1e3:.2f} ms")
+print(" calls   total ms   avg us  kernel")
 for r in rows[:40]:
-    print(f"{r[1]:6d} {r[2] / 1e3:10.1f} {r[3] / 1e3:8.2f}  {r[0][:120]}")
+    print(f"{r[1]:6d} {r[2] / 1e3:10.2f} {r[3]:8.2f}  {r[0][:120]}")
