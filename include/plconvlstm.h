@@ -151,8 +151,9 @@ size_t plc_generator_workspace_offset(const plc_rollout_desc* d, const char* nam
  *   dbias [4Ch] (may be NULL) are overwritten.
  * plc_generator_rollout_bwd: backpropagation through time over the rollout that
  *   plc_generator_rollout_fwd ran with save_for_backward = 1 on the SAME descriptor (its
- *   workspace holds the saved activations).  Writes the gradient of every parameter.
- *   Not available (PLC_EUNSUPPORTED) when the rollout contains a bilinear feature resize.
+ *   workspace holds the saved activations).  Writes the gradient of every parameter, for every
+ *   geometry the forward accepts (PixelShuffle blocks, the residual bilinear resize and the resize
+ *   to target_size, generator.py:174-195, included).
  * ------------------------------------------------------------------------------------- */
 size_t plc_convlstm_cell_bwd_workspace_bytes(int B, int Cin, int Ch, int H, int W);
 int plc_convlstm_cell_bwd(const float* x, const float* h, const float* c,

@@ -218,6 +218,7 @@ struct BwdPlan {
     size_t post2T, post0T, cell1T, cell2T, lu2T, dem2T, upT[8], bpk0;
     size_t d_out8, d_pre0, d_feat, d_pre, d_lu_pre, d_dem_pre, d_lu_mid, d_dem_mid;
     size_t d_conv[8], d_in[8];
+    size_t d_mid, d_up;     // (size_t)-1 when the corresponding bilinear resize is absent
     size_t dz1, dz2, dcat1, dcat2, dc1, dc2, d_pre_init, slab, slab_bytes, total;
 };
 
@@ -226,12 +227,13 @@ static size_t max_sz(size_t a, size_t b) { return a > b ? a : b; }
 static int bwd_plan(const plc_rollout_desc* d, const RolloutPlan& fp, BwdPlan* p) {
     const int C1 = d->C1, C2 = d->C2, B = d->B, T = d->T, NI = d->B * d->T;
     const size_t hw = (size_t)d->H * d->W, ohw = (size_t)d->out_H * d->out_W;
-    if (d->mid_H != fp.up_H || d->mid_W != fp.up_W || d->out_H != d->mid_H || d->out_W != d->mid_W)
-        return plc_fail(PLC_EUNSUPPORTED,
-                        "rollout backward: the bilinear feature resize (non power-of-two scale / target_size) "
-                        "has no backward kernel yet");
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t at = o; o += align256(bytes); return at; };
+    // gradients of the feature map before the resize to target_size / before the residual bilinear resize
+    p->d_mid = (d->out_H != d->mid_H || d->out_W != d->mid_W)
+                   ? take((size_t)NI * (C2 / 8) * d->mid_H * d->mid_W * 16) : (size_t)-1;
+    p->d_up = (d->mid_H != fp.up_H || d->mid_W != fp.up_W)
+                  ? take((size_t)NI * (C2 / 8) * fp.up_H * fp.up_W * 16) : (size_t)-1;
     p->post2T = take(packedT_weight_bytes(1, 32, 0, 3, 1));
     p->post0T = take(packedT_weight_bytes(32, C2, 0, 3, 1));
     p->cell1T = take(packedT_weight_bytes(4 * C1, C1, C1, 3, 1));
@@ -415,6 +417,23 @@ extern "C" int plc_generator_rollout_bwd(const plc_rollout_desc* d, const plc_ro
     }
     // ---- PixelShuffle upsample blocks, last to first ------------------------------------------
     const char* cur = wb + bp.d_pre;     // gradient of the feature map entering the gates
+    // ---- bilinear feature resizes (generator.py:179-195), last to first -------------------------
+    if (bp.d_mid != (size_t)-1) {
+        const long long planes = (long long)NI * (C2 / 8);
+        hipLaunchKernelGGL(plc_resize_cb8_bwd_kernel, dim3(ew_grid(planes * d->mid_H * d->mid_W)), dim3(256), 0, st,
+                           (const uint4*)cur, (uint4*)(wb + bp.d_mid), planes, d->mid_H, d->mid_W, oH, oW,
+                           d->out_scale_h, d->out_scale_w);
+        PLC_HIP(hipGetLastError());
+        cur = wb + bp.d_mid;
+    }
+    if (bp.d_up != (size_t)-1) {
+        const long long planes = (long long)NI * (C2 / 8);
+        hipLaunchKernelGGL(plc_resize_cb8_bwd_kernel, dim3(ew_grid(planes * fp.up_H * fp.up_W)), dim3(256), 0, st,
+                           (const uint4*)cur, (uint4*)(wb + bp.d_up), planes, fp.up_H, fp.up_W, d->mid_H, d->mid_W,
+                           d->mid_scale_h, d->mid_scale_w);
+        PLC_HIP(hipGetLastError());
+        cur = wb + bp.d_up;
+    }
     for (int k = d->n_blocks - 1; k >= 0; --k) {
         const int kh = H << k, kw = W << k;
         const long long khw = (long long)kh * kw;

@@ -2,6 +2,7 @@
 // One thread handles one 16-byte unit = 8 channels of one pixel.
 #pragma once
 #include "plc_common.h"
+#include "plc_misc_kernels.h"
 
 struct F8 {
     float v[8];
@@ -201,5 +202,56 @@ __global__ void plc_pixel_unshuffle_mask_kernel(const char* __restrict__ d_up, c
             r.v[j] = yv > 0.0f ? dv : 0.0f;
         }
         st_bf8(d_conv + idx * 16, r);
+    }
+}
+
+// Backward of plc_resize_cb8_kernel (bilinear, align_corners False), gather form: one thread per
+// SOURCE unit sums w(dst, src) * d_dst over the destination pixels whose interpolation footprint
+// contains it.  The candidate destination range comes from inverting the coordinate map, padded by
+// one on each side, and every candidate is decided by re-evaluating the forward's own coordinate
+// function, so forward and backward use identical weights and no atomics are needed.
+// d_dst: CB8 bf16 [planes][Ho][Wo]; d_src: CB8 bf16 [planes][Hi][Wi]; scales as in the forward (in / out).
+__device__ __forceinline__ void plc_resize_dst_range(int i, float scale, int in_size, int out_size, int& lo, int& hi) {
+    lo = i == 0 ? 0 : (int)floorf(((float)i - 0.5f) / scale - 0.5f) - 1;
+    hi = i == in_size - 1 ? out_size - 1 : (int)ceilf(((float)i + 1.5f) / scale - 0.5f) + 1;
+    lo = lo < 0 ? 0 : lo;
+    hi = hi > out_size - 1 ? out_size - 1 : hi;
+}
+
+__global__ void plc_resize_cb8_bwd_kernel(const uint4* __restrict__ d_dst, uint4* __restrict__ d_src, long long planes,
+                                          int Hi, int Wi, int Ho, int Wo, float sh, float sw) {
+    const long long hwi = (long long)Hi * Wi, hwo = (long long)Ho * Wo;
+    const long long total = planes * hwi;
+    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const int ix = idx % Wi;
+        const int iy = (idx / Wi) % Hi;
+        const long long plane = idx / hwi;
+        int oy_lo, oy_hi, ox_lo, ox_hi;
+        plc_resize_dst_range(iy, sh, Hi, Ho, oy_lo, oy_hi);
+        plc_resize_dst_range(ix, sw, Wi, Wo, ox_lo, ox_hi);
+        const char* p = (const char*)(d_dst + plane * hwo);
+        F8 acc;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc.v[j] = 0.0f;
+        for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+            int y0, y1;
+            float wy;
+            plc_bilinear_coord(oy, sh, Hi, y0, y1, wy);
+            const float ky = (y0 == iy ? 1.0f - wy : 0.0f) + (y1 == iy ? wy : 0.0f);
+            if (ky == 0.0f) continue;
+            for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+                int x0, x1;
+                float wx;
+                plc_bilinear_coord(ox, sw, Wi, x0, x1, wx);
+                const float kx = (x0 == ix ? 1.0f - wx : 0.0f) + (x1 == ix ? wx : 0.0f);
+                if (kx == 0.0f) continue;
+                const F8 g = ld_bf8(p + ((long long)oy * Wo + ox) * 16);
+                const float k = ky * kx;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc.v[j] = __builtin_fmaf(k, g.v[j], acc.v[j]);
+            }
+        }
+        st_bf8((char*)(d_src + idx), acc);
     }
 }

@@ -40,7 +40,12 @@ def npd(d):
     return {k: (v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in d.items()}
 
 
+ONLY = [n for n in os.environ.get("PLC_GOLDEN_ONLY", "").split(",") if n]   # rewrite just these files
+
+
 def save(name, **arrays):
+    if ONLY and name not in ONLY:
+        return
     path = os.path.join(OUT, name)
     np.savez_compressed(path, **npd(arrays))
     print(f"{name}: {os.path.getsize(path) / 1024:.1f} KiB")
@@ -144,6 +149,14 @@ gen_case("gen_s3.npz", 1, 1, 2, 8, 8, 26, dict(scale_factor=3))                 
 gen_case("gen_s6.npz", 2, 1, 2, 8, 8, 27, dict(scale_factor=6))                 # 2 blocks + bilinear x1.5
 gen_case("gen_s2_aux.npz", 1, 2, 2, 8, 8, 28, dict(scale_factor=2), aux_hw=(24, 20))  # aux maps resized
 gen_case("gen_s4_native.npz", 2, 1, 3, 15, 12, 29, dict(scale_factor=4))        # ragged LR, 2 blocks
+# gradients through the bilinear feature resizes (generator.py:179-195)
+RESIZE_GRADS = ("upsample_blocks.0.conv", "init_conv", "cell2.conv.bias", "cell1.conv", "post_process.0",
+                "dem_attn.conv.0", "lu_attn.conv.2")
+gen_case("gen_s3_grads.npz", 1, 2, 2, 10, 7, 41, dict(scale_factor=3), with_grads=RESIZE_GRADS)
+gen_case("gen_grid_grads.npz", 3, 1, 2, 8, 8, 42, dict(target_grid_size=(500, 600)),        # 64x64 -> 53x64
+         fwd_kwargs=dict(input_grid_size=(4000, 4000)), with_grads=RESIZE_GRADS)
+gen_case("gen_grid_mix_grads.npz", 1, 1, 2, 9, 12, 43, dict(target_grid_size=(1000, 900)),   # x2, x1.5, then 27 -> 30 rows
+         fwd_kwargs=dict(input_grid_size=(3000, 3000)), with_grads=RESIZE_GRADS)
 
 
 # ------------------------------------------------------------------ G8: CombinedLoss

@@ -11,6 +11,7 @@ import pytest
 import torch
 
 from conftest import load_golden, master_params
+from oracle import cpu_oracle as O
 
 pytestmark = pytest.mark.gpu
 
@@ -45,7 +46,7 @@ def test_cell_backward(gpu, tag):
         assert e <= TOL, (k, e)
 
 
-def _run_case(gpu, name, n_blocks, ctor):
+def _run_case(gpu, name, n_blocks, ctor, fwd_kw=None, keep_grads=False):
     from pl_convlstm_gan_amd import Generator
     from pl_convlstm_gan_amd.losses import CombinedLoss
     from pl_convlstm_gan_amd.models import UpsampleBlock
@@ -55,8 +56,8 @@ def _run_case(gpu, name, n_blocks, ctor):
     m.load_state_dict(master_params(n_blocks), strict=True)
     m = m.to(gpu)
     rain = g["rain"].to(gpu)
-    out = m(rain, g["dem"].to(gpu), g["lu"].to(gpu))
-    assert out.requires_grad
+    out = m(rain, g["dem"].to(gpu), g["lu"].to(gpu), **(fwd_kw or {}))
+    assert out.requires_grad and tuple(out.shape) == tuple(g["out"].shape)
     loss, _ = CombinedLoss()(out, rain, g["s_coords"].to(gpu), g["s_values"].to(gpu), out.shape[-2] / rain.shape[-2])
     loss.backward()
     assert abs(float(loss.detach()) - float(g["loss"])) <= 2e-2 * abs(float(g["loss"]))
@@ -66,6 +67,8 @@ def _run_case(gpu, name, n_blocks, ctor):
             p = dict(m.named_parameters())[k[5:]]
             assert p.grad is not None, k
             errs[k[5:]] = (relmax(p.grad.cpu(), v), rel_l2(p.grad.cpu(), v))
+    if keep_grads:
+        errs["_grads"] = {k: p.grad.cpu() for k, p in m.named_parameters()}
     return errs
 
 
@@ -110,9 +113,32 @@ def test_backward_is_repeatable_and_workspace_safe(gpu):
         assert torch.isfinite(x).all()
 
 
-def test_resize_backward_is_refused(gpu):
-    from pl_convlstm_gan_amd import Generator
-    m = Generator(hidden_dims=[16, 32], lu_channels=5, scale_factor=3).to(gpu)
-    out = m(torch.rand(1, 2, 1, 8, 8, device=gpu), torch.rand(1, 1, 24, 24, device=gpu), torch.rand(1, 5, 24, 24, device=gpu))
-    with pytest.raises(NotImplementedError):
-        out.sum().backward()
+@pytest.mark.parametrize("name,n_blocks,ctor,fwd_kw", [
+    # 1 block, then F.interpolate x1.5 (generator.py:179-185)
+    ("gen_s3_grads.npz", 1, dict(scale_factor=3), {}),
+    # 3 blocks, then the resize to target_size, 64 -> 53 rows (generator.py:188-195)
+    ("gen_grid_grads.npz", 3, dict(target_grid_size=(500, 600)), dict(input_grid_size=(4000, 4000))),
+    # 1 block, x1.67 residual resize AND the resize to target_size
+    ("gen_grid_mix_grads.npz", 1, dict(target_grid_size=(1000, 900)), dict(input_grid_size=(3000, 3000))),
+])
+def test_generator_param_grads_through_bilinear_resize(gpu, name, n_blocks, ctor, fwd_kw):
+    """Two checks.  (1) Against the reference's autograd goldens at the usual bf16 tolerance -- except
+    the stem (init_conv) of these 70-100 pixel cases: its gradient passes the stem ReLU and the L1
+    signs of the loss, and bf16 storage flips enough of them that the oracle's own bf16 emulation
+    is 21 % (max) / 7.8 % (L2) away from the fp32 golden on gen_s3_grads; there the bound is 0.25 / 0.1.
+    (2) Against the oracle's bf16-storage emulation (same rounding points as the engine), every
+    parameter within 2e-2 (measured 0.2-0.6 %): this is the check that pins the resize backward."""
+    errs = _run_case(gpu, name, n_blocks, ctor, fwd_kw, keep_grads=True)
+    grads = errs.pop("_grads")
+    print(errs)
+    assert "upsample_blocks.0.conv.weight" in errs and "cell1.conv.weight" in errs
+    for k, (emax, el2) in errs.items():
+        if k.startswith("init_conv."):
+            assert emax <= 0.25 and el2 <= 0.1, (k, emax, el2)
+        else:
+            assert emax <= TOL_MAX and el2 <= TOL_L2, (k, emax, el2)
+    g = load_golden(name)
+    _, emu, _ = O.grads_of(master_params(n_blocks), g["rain"], g["dem"], g["lu"], g["s_coords"], g["s_values"],
+                           fwd_kw=dict(emulate="bf16", **ctor, **fwd_kw))
+    for k, v in grads.items():
+        assert relmax(v, emu[k]) <= 2e-2 and rel_l2(v, emu[k]) <= 2e-2, (k, relmax(v, emu[k]), rel_l2(v, emu[k]))

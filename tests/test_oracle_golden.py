@@ -25,6 +25,9 @@ GEN_CASES = {
     "gen_s6.npz": (2, dict(scale_factor=6)),
     "gen_s2_aux.npz": (1, dict(scale_factor=2)),
     "gen_s4_native.npz": (2, dict(scale_factor=4)),
+    "gen_s3_grads.npz": (1, dict(scale_factor=3)),
+    "gen_grid_grads.npz": (3, dict(target_grid_size=(500, 600), input_grid_size=(4000, 4000))),
+    "gen_grid_mix_grads.npz": (1, dict(target_grid_size=(1000, 900), input_grid_size=(3000, 3000))),
 }
 
 
@@ -51,7 +54,8 @@ def test_generator_forward(name):
     assert float((out - g["out"]).abs().max()) <= ATOL
 
 
-@pytest.mark.parametrize("name", ["gen_s1.npz", "gen_s2.npz"])
+@pytest.mark.parametrize("name", ["gen_s1.npz", "gen_s2.npz", "gen_s3_grads.npz", "gen_grid_grads.npz",
+                                  "gen_grid_mix_grads.npz"])
 def test_generator_param_grads(name):
     n_blocks, kw = GEN_CASES[name]
     g = load_golden(name)
