@@ -20,8 +20,9 @@ __global__ void plc_plane_to_cb8_kernel(PlcTensor src, int n_in, int N, long lon
 // weight gradient launcher
 // ---------------------------------------------------------------------------------------------
 // Persistent workgroups per launch: one per CU when the LDS double buffer fills the CU, two when
-// two fit (the small-channel convs, whose per-tile MFMA work is shorter than a global-load round
-// trip: a second resident workgroup hides that latency).
+// two fit.  (The kernel is bound by LDS read bandwidth -- both MFMA operands come from LDS through
+// transposing reads, 1.2 KB per MFMA for cell 2 -- not by global latency: staging the tiles by
+// LDS-DMA two tiles ahead was measured and changed nothing.)
 template <int NCB0, int NCB1, int MT, int KS>
 static constexpr int wgrad_max_blocks() {
     return WgradGeom<NCB0 + NCB1, MT, KS>::LDS_BYTES <= 80 * 1024 ? 512 : 256;
@@ -438,7 +439,7 @@ extern "C" int plc_generator_rollout_bwd(const plc_rollout_desc* d, const plc_ro
         const int kh = H << k, kw = W << k;
         const long long khw = (long long)kh * kw;
         const char* in_k = (k == 0) ? wf + fp.h2s + (size_t)B * fp.img2 : wf + fp.up_out[k - 1];
-        hipLaunchKernelGGL(plc_pixel_unshuffle_mask_kernel, dim3(ew_grid((long long)NI * (4 * C2 / 8) * khw)), dim3(256),
+        hipLaunchKernelGGL(plc_pixel_unshuffle_mask_kernel, dim3(ew_grid((long long)NI * (C2 / 8) * khw)), dim3(256),
                            0, st, cur, (const char*)(wf + fp.up_out[k]), wb + bp.d_conv[k], NI, C2, kh, kw);
         PLC_HIP(hipGetLastError());
         ConvArgs in = conv_args(kh, kw, NI);

@@ -180,28 +180,35 @@ __global__ void plc_relu_mask_kernel(Cb8View d, Cb8View mask, char* out, long lo
 // d_up[c][2y+i][2x+j] : 0.   d_up / y_up: CB8 bf16 [N][C/8][2H][2W]; d_conv: CB8 bf16 [N][4C/8][H][W].
 __global__ void plc_pixel_unshuffle_mask_kernel(const char* __restrict__ d_up, const char* __restrict__ y_up,
                                                 char* __restrict__ d_conv, int N, int C, int H, int W) {
+    // One thread per (image, up-sampled channel block, low-res pixel): it reads the 2x2 quad of
+    // 16-byte units of d_up and y_up (every byte used) and writes the four conv-channel units
+    // 4*cb + k, k = 0..3, which hold channels c = 2k, 2k+1 of the block at the four quad positions.
     const long long hw = (long long)H * W;
-    const int ocb = 4 * C / 8;
-    const long long total = (long long)N * ocb * hw;
+    const int ucb = C / 8;
+    const long long total = (long long)N * ucb * hw;
     const long long W2 = 2 * W, hw2 = 4 * hw;
     for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
          idx += (long long)gridDim.x * blockDim.x) {
         const int x = idx % W;
         const int y = (idx / W) % H;
-        const int cb = (idx / hw) % ocb;
-        const long long n = idx / (hw * ocb);
-        F8 r;
+        const int cb = (idx / hw) % ucb;
+        const long long n = idx / (hw * ucb);
+        const long long up0 = ((n * ucb + cb) * hw2 + (long long)(2 * y) * W2 + 2 * x) * 16;
+        F8 g[4];   // g[sub].v[c] = masked gradient of channel c at quad position sub = 2i + j
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int o = 8 * cb + j;
-            const int c = o >> 2, sub = o & 3;
-            const long long pix2 = (long long)(2 * y + (sub >> 1)) * W2 + 2 * x + (sub & 1);
-            const long long e = (((n * (C / 8) + (c >> 3)) * hw2 + pix2) * 8 + (c & 7)) * 2;
-            const float dv = bf2f(*(const unsigned short*)(d_up + e));
-            const float yv = bf2f(*(const unsigned short*)(y_up + e));
-            r.v[j] = yv > 0.0f ? dv : 0.0f;
+        for (int sub = 0; sub < 4; ++sub) {
+            const long long o = up0 + ((long long)(sub >> 1) * W2 + (sub & 1)) * 16;
+            const F8 dv = ld_bf8(d_up + o), yv = ld_bf8(y_up + o);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) g[sub].v[c] = yv.v[c] > 0.0f ? dv.v[c] : 0.0f;
         }
-        st_bf8(d_conv + idx * 16, r);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            F8 r;   // conv channels 8k..8k+7 of this block's 32: channel 4c + sub, c = 2k, 2k+1
+#pragma unroll
+            for (int j = 0; j < 8; ++j) r.v[j] = g[j & 3].v[2 * k + (j >> 2)];
+            st_bf8(d_conv + (((n * (4 * ucb) + 4 * cb + k) * hw) + (long long)y * W + x) * 16, r);
+        }
     }
 }
 
