@@ -183,7 +183,8 @@ static int launch_conv_th(ConvArgs a, int n_img, int n_mgroups, hipStream_t st) 
 template <int NCB0, int NCB1, int NMT, int KS, int STAGE, int EPI>
 static int launch_conv(ConvArgs a, int n_img, int n_mgroups, hipStream_t st) {
     const long long t16 = (long long)n_img * cdiv(a.H, 16) * cdiv(a.W, 32) * n_mgroups;
-    if (t16 >= 512 && NMT != 1) return launch_conv_th<NCB0, NCB1, NMT, KS, STAGE, EPI, 16>(a, n_img, n_mgroups, st);
+    // (single-M-tile convs whose staging is not plain DMA were measured faster with 8-row tiles)
+    if (t16 >= 512 && !(NMT == 1 && STAGE != STAGE_CB8)) return launch_conv_th<NCB0, NCB1, NMT, KS, STAGE, EPI, 16>(a, n_img, n_mgroups, st);
     return launch_conv_th<NCB0, NCB1, NMT, KS, STAGE, EPI, 8>(a, n_img, n_mgroups, st);
 }
 

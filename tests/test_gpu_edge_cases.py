@@ -1,0 +1,69 @@
+"""Edge geometries of the rollout (forward and parameter gradients) on the engine against the CPU
+oracle: single time step, tiny and one-pixel-wide grids, odd batch, 1 / 9 / 16 land-use channels,
+auxiliary maps at another resolution, with randomly initialised parameters (not the golden ones).
+
+The oracle's fp32 path is pinned to the reference by the goldens; its bf16-storage emulation rounds
+where the engine rounds.  Bounds: forward <= 2e-2 * max|ref| vs fp32 and <= 4e-3 vs the emulation
+(the tolerances of test_gpu_parity_fwd.py); gradients vs the emulation <= 3e-2 (max and L2; these
+cases have few pixels, see test_gpu_parity_bwd.py on why the fp32 gradients are not the yardstick)."""
+import pytest
+import torch
+
+from oracle import cpu_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    # B, T, H, W, scale, L, aux_hw
+    (1, 1, 8, 8, 1, 5, None),        # T == 1 (the loss's temporal term is NaN there: gradients via sum())
+    (3, 2, 3, 5, 1, 1, None),        # grid smaller than one tile, one land-use channel, odd batch
+    (2, 2, 1, 40, 1, 9, None),       # one-pixel-high grid crossing a tile boundary in x, two LU blocks
+    (1, 2, 33, 17, 1, 16, None),     # just past a tile boundary in y, the maximum of 16 LU channels
+    (2, 3, 6, 4, 2, 5, (7, 9)),      # one upsample block, aux maps at an unrelated resolution
+    (1, 2, 5, 6, 4, 3, None),        # two upsample blocks
+]
+
+
+def relmax(a, b):
+    return float((a - b).abs().max()) / max(float(b.abs().max()), 1e-20)
+
+
+def rel_l2(a, b):
+    return float((a - b).norm()) / max(float(b.norm()), 1e-20)
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_edge_geometry_forward_and_grads(gpu, case):
+    from pl_convlstm_gan_amd import Generator
+    B, T, H, W, s, L, aux_hw = case
+    torch.manual_seed(100 + H * W + L)
+    m = Generator(hidden_dims=[16, 32], lu_channels=L, scale_factor=s)
+    gen = torch.Generator().manual_seed(7 + B + T)
+    rain = 10 * torch.rand(B, T, 1, H, W, generator=gen) * (torch.rand(B, T, 1, H, W, generator=gen) > 0.5)
+    ah, aw = aux_hw if aux_hw else (H * s, W * s)
+    dem = torch.rand(B, 1, ah, aw, generator=gen)
+    lu = torch.rand(B, L, ah, aw, generator=gen)
+    m = m.to(gpu)
+    out = m(rain.to(gpu), dem.to(gpu), lu.to(gpu))          # creates the lazy blocks, with autograd
+    params = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    assert out.shape == (B, T, 1, H * s, W * s)
+
+    ref = O.generator_forward(params, rain, dem, lu, scale_factor=s)
+    leaf = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    emu = O.generator_forward(leaf, rain, dem, lu, scale_factor=s, emulate="bf16")
+    scale = float(ref.abs().max())
+    assert relmax(out.detach().cpu(), ref) <= 2e-2
+    assert float((out.detach().cpu() - emu.detach()).abs().max()) <= 4e-3 * scale
+
+    # a smooth scalar of the output: gradient = a fixed positive random field (no L1 sign flips, and
+    # no cancellation in the bias gradients, whose incoming gradient the engine carries as bf16)
+    wgt = torch.rand(out.shape, generator=gen) + 0.5
+    (out * wgt.to(gpu)).sum().backward()
+    (emu * wgt).sum().backward()
+    worst = {}
+    for k, p in m.named_parameters():
+        g_ref = leaf[k].grad
+        worst[k] = (relmax(p.grad.cpu(), g_ref), rel_l2(p.grad.cpu(), g_ref))
+    print(case, {k: (round(a, 4), round(b, 4)) for k, (a, b) in worst.items()})
+    for k, (emax, el2) in worst.items():
+        assert emax <= 3e-2 and el2 <= 3e-2, (k, emax, el2)
