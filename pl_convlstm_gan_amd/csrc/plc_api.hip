@@ -102,6 +102,51 @@ extern "C" size_t plc_packed_bias_bytes(int cout) {
     return align256((size_t)pack_nmt(cout) * 32 * sizeof(float));
 }
 
+static int pack_blocks(long long elems) {
+    const long long b = (elems + 255) / 256;
+    return (int)(b < 1 ? 1 : (b > 64 ? 64 : b));
+}
+
+// Forward packing job (rows = output channels regrouped per `mode`).
+static PackJob pack_job(const float* w, const float* bias, void* wpk, float* bpk, int cout, int c0, int c1, int ks,
+                        int mode) {
+    PackJob jb;
+    memset(&jb, 0, sizeof(jb));
+    jb.w = w; jb.bias = bias; jb.wpk = (unsigned short*)wpk; jb.bpk = bpk;
+    jb.cout = cout; jb.c0 = c0; jb.c1 = c1; jb.ks = ks; jb.mode = mode;
+    jb.n_mt = pack_nmt(cout); jb.nks_w = pack_nks(c0, c1, ks);
+    jb.ch_per_gate = cout / 4; jb.transposed = 0; jb.ksplit = 1;
+    jb.n_blocks = pack_blocks((long long)jb.n_mt * jb.nks_w * 512);
+    return jb;
+}
+
+// Jobs collected for one launch of plc_pack_multi_kernel.
+struct PackBatch {
+    PackTable tb;
+    int blocks;
+};
+static void pack_batch_begin(PackBatch* b) {
+    b->tb.n = 0;
+    b->blocks = 0;
+}
+static int pack_batch_flush(PackBatch* b, hipStream_t st) {
+    if (b->tb.n == 0) return PLC_OK;
+    hipLaunchKernelGGL(plc_pack_multi_kernel, dim3(b->blocks), dim3(256), 0, st, b->tb);
+    PLC_HIP(hipGetLastError());
+    pack_batch_begin(b);
+    return PLC_OK;
+}
+static int pack_batch_add(PackBatch* b, PackJob jb, hipStream_t st) {
+    if (b->tb.n == PACK_MAX_JOBS) {
+        int rc = pack_batch_flush(b, st);
+        if (rc) return rc;
+    }
+    jb.first_block = b->blocks;
+    b->blocks += jb.n_blocks;
+    b->tb.job[b->tb.n++] = jb;
+    return PLC_OK;
+}
+
 extern "C" int plc_pack_conv_weight(const float* w, const float* bias, void* wpk, float* bpk,
                                     int cout, int c0, int c1, int ks, int mode, void* stream) {
     PLC_REQUIRE(w && wpk && bpk, "plc_pack_conv_weight: null pointer");
@@ -109,10 +154,8 @@ extern "C" int plc_pack_conv_weight(const float* w, const float* bias, void* wpk
     PLC_REQUIRE(mode >= 0 && mode <= 2, "plc_pack_conv_weight: bad mode %d", mode);
     if (mode != PLC_PACK_PLAIN) PLC_REQUIRE(cout % 32 == 0, "plc_pack_conv_weight: cout %d must be a multiple of 32 for mode %d", cout, mode);
     PLC_REQUIRE(aligned16(wpk) && aligned16(bpk), "plc_pack_conv_weight: packed buffers must be 16-byte aligned");
-    const int n_mt = pack_nmt(cout), nks = pack_nks(c0, c1, ks);
-    const long long total = (long long)n_mt * nks * 512;
-    hipLaunchKernelGGL(plc_pack_weight_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream,
-                       w, bias, (unsigned short*)wpk, bpk, cout, c0, c1, ks, mode, n_mt, nks, cout / 4, 0, 1);
+    const PackJob jb = pack_job(w, bias, wpk, bpk, cout, c0, c1, ks, mode);
+    hipLaunchKernelGGL(plc_pack_weight_kernel, dim3(jb.n_blocks), dim3(256), 0, (hipStream_t)stream, jb);
     PLC_HIP(hipGetLastError());
     return PLC_OK;
 }
@@ -124,12 +167,20 @@ static inline int packT_nks(int cout, int ks, int ksplit) { return (ks * ks * (c
 static size_t packedT_weight_bytes(int cout, int c0, int c1, int ks, int ksplit) {
     return align256((size_t)packT_nmt(c0, c1) * ksplit * packT_nks(cout, ks, ksplit) * 64 * 16);
 }
+static PackJob pack_job_T(const float* w, void* wpk, float* bpk, int cout, int c0, int c1, int ks, int ksplit) {
+    PackJob jb;
+    memset(&jb, 0, sizeof(jb));
+    jb.w = w; jb.wpk = (unsigned short*)wpk; jb.bpk = bpk;
+    jb.cout = cout; jb.c0 = c0; jb.c1 = c1; jb.ks = ks;
+    jb.n_mt = packT_nmt(c0, c1); jb.nks_w = packT_nks(cout, ks, ksplit);
+    jb.transposed = 1; jb.ksplit = ksplit;
+    jb.n_blocks = pack_blocks((long long)jb.n_mt * ksplit * jb.nks_w * 512);
+    return jb;
+}
 static int pack_conv_weight_T(const float* w, void* wpk, float* bpk, int cout, int c0, int c1, int ks, int ksplit,
                               hipStream_t st) {
-    const int n_mt = packT_nmt(c0, c1), nks = packT_nks(cout, ks, ksplit);
-    const long long total = (long long)n_mt * ksplit * nks * 512;
-    hipLaunchKernelGGL(plc_pack_weight_kernel, dim3(ew_grid(total)), dim3(256), 0, st, w, (const float*)nullptr,
-                       (unsigned short*)wpk, bpk, cout, c0, c1, ks, 0, n_mt, nks, 0, 1, ksplit);
+    const PackJob jb = pack_job_T(w, wpk, bpk, cout, c0, c1, ks, ksplit);
+    hipLaunchKernelGGL(plc_pack_weight_kernel, dim3(jb.n_blocks), dim3(256), 0, st, jb);
     PLC_HIP(hipGetLastError());
     return PLC_OK;
 }
@@ -428,8 +479,10 @@ extern "C" int plc_generator_rollout_fwd(const plc_rollout_desc* d, void* stream
     const long long hw = (long long)H * W, ohw = (long long)oH * oW;
 
     // ---- parameters -> MFMA fragment order ----------------------------------------------
+    PackBatch batch;
+    pack_batch_begin(&batch);
     auto pack = [&](const float* w, const float* b, const Packed& q, int cout, int c0, int c1, int ks, int mode) {
-        return plc_pack_conv_weight(w, b, ws + q.w, (float*)(ws + q.b), cout, c0, c1, ks, mode, stream);
+        return pack_batch_add(&batch, pack_job(w, b, ws + q.w, (float*)(ws + q.b), cout, c0, c1, ks, mode), st);
     };
     if ((rc = pack(d->init_w, d->init_b, p.init, C1, 3, 0, 3, PLC_PACK_PLAIN))) return rc;
     if ((rc = pack(d->cell1_w, d->cell1_b, p.cell1, 4 * C1, C1, C1, 3, PLC_PACK_LSTM))) return rc;
@@ -442,6 +495,7 @@ extern "C" int plc_generator_rollout_fwd(const plc_rollout_desc* d, void* stream
         if ((rc = pack(d->up_w[k], d->up_b[k], p.up[k], 4 * C2, C2, 0, 3, PLC_PACK_PIXSHUF))) return rc;
     if ((rc = pack(d->post0_w, d->post0_b, p.post0, 32, C2, 0, 3, PLC_PACK_PLAIN))) return rc;
     if ((rc = pack(d->post2_w, d->post2_b, p.post2, 1, 32, 0, 3, PLC_PACK_PLAIN))) return rc;
+    if ((rc = pack_batch_flush(&batch, st))) return rc;
 
     // ---- t-invariant gates: sigmoid(conv1x1(relu(conv3x3(aux)))) for DEM and land use, multiplied
     {
@@ -510,24 +564,33 @@ extern "C" int plc_generator_rollout_fwd(const plc_rollout_desc* d, void* stream
     }
 
     // ---- recurrence -----------------------------------------------------------------------
-    PLC_HIP(hipMemsetAsync(ws + p.h1s, 0, (size_t)B * p.img1, st));
-    PLC_HIP(hipMemsetAsync(ws + p.c1s, 0, (size_t)B * p.img1 * 2, st));
-    PLC_HIP(hipMemsetAsync(ws + p.h2s, 0, (size_t)B * p.img2, st));
-    PLC_HIP(hipMemsetAsync(ws + p.c2s, 0, (size_t)B * p.img2 * 2, st));
     {
         const size_t s1 = (size_t)B * p.img1, s2 = (size_t)B * p.img2;
         const bool save = d->save_for_backward != 0;
+        // The initial states are zero (generator.py:156-160).  The step-0 cells do not read them
+        // (zero_state); slot 0 of the state arrays is only cleared when the backward pass, whose
+        // batched kernels read every slot, will follow.
+        if (save) {
+            PLC_HIP(hipMemsetAsync(ws + p.h1s, 0, s1, st));
+            PLC_HIP(hipMemsetAsync(ws + p.c1s, 0, s1 * 2, st));
+            PLC_HIP(hipMemsetAsync(ws + p.h2s, 0, s2, st));
+            PLC_HIP(hipMemsetAsync(ws + p.c2s, 0, s2 * 2, st));
+        }
         auto cell1 = [&](int t) {
-            return cell_conv_args(ws + p.xs + t * s1, ws + p.h1s + t * s1, (const float*)(ws + p.c1s + t * s1 * 2),
-                                  ws + p.cell1.w, (const float*)(ws + p.cell1.b), ws + p.h1s + (t + 1) * s1,
-                                  (float*)(ws + p.c1s + (t + 1) * s1 * 2),
-                                  save ? ws + p.gates1 + (size_t)t * s1 * 4 : nullptr, B, C1, C1, H, W);
+            ConvArgs a = cell_conv_args(ws + p.xs + t * s1, ws + p.h1s + t * s1, (const float*)(ws + p.c1s + t * s1 * 2),
+                                        ws + p.cell1.w, (const float*)(ws + p.cell1.b), ws + p.h1s + (t + 1) * s1,
+                                        (float*)(ws + p.c1s + (t + 1) * s1 * 2),
+                                        save ? ws + p.gates1 + (size_t)t * s1 * 4 : nullptr, B, C1, C1, H, W);
+            a.zero_state = t == 0;
+            return a;
         };
         auto cell2 = [&](int t) {
-            return cell_conv_args(ws + p.h1s + (t + 1) * s1, ws + p.h2s + t * s2, (const float*)(ws + p.c2s + t * s2 * 2),
-                                  ws + p.cell2.w, (const float*)(ws + p.cell2.b), ws + p.h2s + (t + 1) * s2,
-                                  (float*)(ws + p.c2s + (t + 1) * s2 * 2),
-                                  save ? ws + p.gates2 + (size_t)t * s2 * 4 : nullptr, B, C1, C2, H, W);
+            ConvArgs a = cell_conv_args(ws + p.h1s + (t + 1) * s1, ws + p.h2s + t * s2, (const float*)(ws + p.c2s + t * s2 * 2),
+                                        ws + p.cell2.w, (const float*)(ws + p.cell2.b), ws + p.h2s + (t + 1) * s2,
+                                        (float*)(ws + p.c2s + (t + 1) * s2 * 2),
+                                        save ? ws + p.gates2 + (size_t)t * s2 * 4 : nullptr, B, C1, C2, H, W);
+            a.zero_state = t == 0;
+            return a;
         };
         // (Running cell 1 of step t+1 in the same launch as cell 2 of step t was measured: the two
         // kinds of workgroup share each SIMD's matrix pipe and finish together, so nothing is gained.)

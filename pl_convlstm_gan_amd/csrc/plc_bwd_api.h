@@ -34,13 +34,48 @@ static size_t wgrad_slab_bytes() {
     return align256((size_t)wgrad_max_blocks<NCB0, NCB1, MT, KS>() * (MT * 32) * (G::NT * 32) * sizeof(float));
 }
 
+// Slab memory of a backward pass and the pending reductions over it.  Weight-gradient launches
+// carve their slabs from the arena and queue a reduction job; arena_flush reduces everything
+// queued in ONE launch (normally once, at the end of the pass) and recycles the memory.  When the
+// arena or the job table is full the pending jobs are flushed early, so any arena that holds the
+// largest single slab works.
+struct SlabArena {
+    char* base;
+    size_t size, used;
+    FinalizeTable tb;
+    int blocks;
+};
+static void arena_begin(SlabArena* ar, void* base, size_t size) {
+    ar->base = (char*)base;
+    ar->size = size;
+    ar->used = 0;
+    ar->tb.n = 0;
+    ar->blocks = 0;
+}
+static int arena_flush(SlabArena* ar, hipStream_t st) {
+    if (ar->tb.n > 0) {
+        hipLaunchKernelGGL(plc_wgrad_finalize_multi_kernel, dim3(ar->blocks), dim3(256), 0, st, ar->tb);
+        PLC_HIP(hipGetLastError());
+    }
+    ar->used = 0;
+    ar->tb.n = 0;
+    ar->blocks = 0;
+    return PLC_OK;
+}
+
 // `in` carries H, W, n_in and the staging tensors of the conv input; dz has mcb_valid channel blocks.
 template <int NCB0, int NCB1, int MT, int KS, int STAGE>
-static int launch_wgrad(ConvArgs in, PlcTensor dz, int mcb_valid, int n_img, float* slab, size_t slab_bytes,
+static int launch_wgrad(ConvArgs in, PlcTensor dz, int mcb_valid, int n_img, SlabArena* ar,
                         float* dw, float* db, int cout, int c0, int c1, hipStream_t st) {
     using G = WgradGeom<NCB0 + NCB1, MT, KS>;
-    if (slab_bytes < wgrad_slab_bytes<NCB0, NCB1, MT, KS>())
-        return plc_fail(PLC_EWORKSPACE, "wgrad: slab %zu < %zu bytes", slab_bytes, wgrad_slab_bytes<NCB0, NCB1, MT, KS>());
+    const size_t need = wgrad_slab_bytes<NCB0, NCB1, MT, KS>();
+    if (ar->used + need > ar->size || ar->tb.n == FINALIZE_MAX_JOBS) {
+        int rc = arena_flush(ar, st);
+        if (rc) return rc;
+    }
+    if (need > ar->size) return plc_fail(PLC_EWORKSPACE, "wgrad: slab arena %zu < %zu bytes", ar->size, need);
+    float* slab = (float*)(ar->base + ar->used);
+    ar->used += need;
     WgradArgs a;
     memset(&a, 0, sizeof(a));
     a.in = in;
@@ -56,10 +91,16 @@ static int launch_wgrad(ConvArgs in, PlcTensor dz, int mcb_valid, int n_img, flo
     PLC_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), G::LDS_BYTES, st, a);
     PLC_HIP(hipGetLastError());
-    const long long total = (long long)cout * G::NT * 32;
-    hipLaunchKernelGGL(plc_wgrad_finalize_kernel, dim3(ew_grid(total * 8)), dim3(256), 0, st, (const float*)slab, grid,
-                       MT * 32, G::NT * 32, dw, db, cout, c0, c1, KS, NCB0 + NCB1);
-    PLC_HIP(hipGetLastError());
+    FinalizeJob jb;
+    memset(&jb, 0, sizeof(jb));
+    jb.slab = slab; jb.dw = dw; jb.db = db;
+    jb.n_slabs = grid; jb.rows_pad = MT * 32; jb.cols_pad = G::NT * 32;
+    jb.cout = cout; jb.c0 = c0; jb.c1 = c1; jb.ks = KS; jb.ncb = NCB0 + NCB1;
+    const long long groups = ((long long)cout * G::NT * 32 + 31) / 32;      // 32 output elements per block pass
+    jb.n_blocks = (int)(groups < 1 ? 1 : (groups > 1024 ? 1024 : groups));
+    jb.first_block = ar->blocks;
+    ar->blocks += jb.n_blocks;
+    ar->tb.job[ar->tb.n++] = jb;
     return PLC_OK;
 }
 
@@ -102,7 +143,7 @@ static int cell_dgrad(const void* dz, const void* wpkT, const float* bpk0, void*
 }
 static int cell_dgrad_ksplit(int Cin, int Ch) { return (Cin == 16 && Ch == 32) ? 2 : 1; }
 
-static int cell_wgrad(const void* dz, PlcTensor x, PlcTensor h, int n_in, int n_img, float* slab, size_t slab_bytes,
+static int cell_wgrad(const void* dz, PlcTensor x, PlcTensor h, int n_in, int n_img, SlabArena* slab,
                       float* dw, float* db, int Cin, int Ch, int H, int W, hipStream_t st) {
     const long long hw = (long long)H * W;
     ConvArgs in = conv_args(H, W, n_in);
@@ -110,9 +151,9 @@ static int cell_wgrad(const void* dz, PlcTensor x, PlcTensor h, int n_in, int n_
     in.src1 = h;
     PlcTensor dzt = tens(dz, (4 * Ch / 8) * hw * 16, (long long)n_in * (4 * Ch / 8) * hw * 16);
     if (Cin == 16 && Ch == 16)
-        return launch_wgrad<2, 2, 2, 3, STAGE_CB8>(in, dzt, 8, n_img, slab, slab_bytes, dw, db, 64, 16, 16, st);
+        return launch_wgrad<2, 2, 2, 3, STAGE_CB8>(in, dzt, 8, n_img, slab, dw, db, 64, 16, 16, st);
     if (Cin == 16 && Ch == 32)
-        return launch_wgrad<2, 4, 4, 3, STAGE_CB8>(in, dzt, 16, n_img, slab, slab_bytes, dw, db, 128, 16, 32, st);
+        return launch_wgrad<2, 4, 4, 3, STAGE_CB8>(in, dzt, 16, n_img, slab, dw, db, 128, 16, 32, st);
     return plc_fail(PLC_EUNSUPPORTED, "ConvLSTM cell backward (Cin=%d, Ch=%d) is outside the compiled kernel set", Cin, Ch);
 }
 static size_t cell_wgrad_slab_bytes(int Cin, int Ch) {
@@ -193,9 +234,12 @@ extern "C" int plc_convlstm_cell_bwd(const float* x, const float* h, const float
     if ((rc = cell_dgrad(ws + s.dz, ws + s.wpkT, (const float*)(ws + s.bpk0), ws + s.dcat, B, Cin, Ch, H, W, st)))
         return rc;
     // weight gradient
+    SlabArena arena;
+    arena_begin(&arena, ws + s.slab, cell_wgrad_slab_bytes(Cin, Ch));
     if ((rc = cell_wgrad(ws + s.dz, tens(ws + s.f.x, (Cin / 8) * hw * 16, 0), tens(ws + s.f.h, (Ch / 8) * hw * 16, 0),
-                         B, B, (float*)(ws + s.slab), cell_wgrad_slab_bytes(Cin, Ch), dweight, dbias, Cin, Ch, H, W, st)))
+                         B, B, &arena, dweight, dbias, Cin, Ch, H, W, st)))
         return rc;
+    if ((rc = arena_flush(&arena, st))) return rc;
     // back to the boundary layout: dcat = [dx (Cin) | dh (Ch)] per image
     {
         const long long cat_img = ((Cin + Ch) / 8) * hw * 16;
@@ -263,13 +307,13 @@ static int bwd_plan(const plc_rollout_desc* d, const RolloutPlan& fp, BwdPlan* p
     p->dc1 = take((size_t)2 * B * (C1 / 8) * hw * 32);
     p->dc2 = take((size_t)2 * B * (C2 / 8) * hw * 32);
     p->d_pre_init = take((size_t)NI * (C1 / 8) * hw * 16);
-    size_t sb = wgrad_slab_bytes<2, 4, 4, 3>();
-    sb = max_sz(sb, wgrad_slab_bytes<2, 2, 2, 3>());
-    sb = max_sz(sb, wgrad_slab_bytes<4, 0, 1, 3>());
-    sb = max_sz(sb, wgrad_slab_bytes<4, 0, 4, 3>());
-    sb = max_sz(sb, wgrad_slab_bytes<2, 0, 1, 3>());
-    sb = max_sz(sb, wgrad_slab_bytes<1, 0, 1, 3>());
-    sb = max_sz(sb, wgrad_slab_bytes<2, 0, 1, 1>());
+    // slab arena: the slabs of every weight-gradient launch of the pass, so one reduction at the end serves all
+    size_t sb = wgrad_slab_bytes<2, 4, 4, 3>() + wgrad_slab_bytes<2, 2, 2, 3>();            // cell 2, cell 1
+    sb += 2 * wgrad_slab_bytes<4, 0, 1, 3>();                                                // post0, post2
+    sb += wgrad_slab_bytes<1, 0, 1, 3>();                                                    // stem
+    sb += 2 * wgrad_slab_bytes<2, 0, 1, 1>();                                                // the two 1x1 gate convs
+    sb += wgrad_slab_bytes<1, 0, 1, 3>() + max_sz(wgrad_slab_bytes<1, 0, 1, 3>(), wgrad_slab_bytes<2, 0, 1, 3>());
+    sb += (size_t)d->n_blocks * wgrad_slab_bytes<4, 0, 4, 3>();                              // upsample blocks
     p->slab_bytes = sb;
     p->slab = take(sb);
     p->total = o;
@@ -312,21 +356,31 @@ extern "C" int plc_generator_rollout_bwd(const plc_rollout_desc* d, const plc_ro
     const int B = d->B, T = d->T, H = d->H, W = d->W, C1 = d->C1, C2 = d->C2, L = d->L, NI = B * T;
     const int oH = d->out_H, oW = d->out_W;
     const long long hw = (long long)H * W, ohw = (long long)oH * oW;
-    float* slab = (float*)(wb + bp.slab);
+    SlabArena arena;
+    arena_begin(&arena, wb + bp.slab, bp.slab_bytes);
+    SlabArena* const slab = &arena;
     const float* bpk0 = (const float*)(wb + bp.bpk0);
     const int mcb = cdiv(C2 / 2, 8);
     const long long fimg = (C2 / 8) * ohw * 16;   // one C2-channel image at output resolution
 
     PLC_HIP(hipMemsetAsync(wb + bp.bpk0, 0, 8 * 32 * sizeof(float), st));
     // ---- transposed (data-gradient) weights -------------------------------------------------
-    if ((rc = pack_conv_weight_T(d->post2_w, wb + bp.post2T, nullptr, 1, 32, 0, 3, 1, st))) return rc;
-    if ((rc = pack_conv_weight_T(d->post0_w, wb + bp.post0T, nullptr, 32, C2, 0, 3, 1, st))) return rc;
-    if ((rc = pack_conv_weight_T(d->cell1_w, wb + bp.cell1T, nullptr, 4 * C1, C1, C1, 3, 1, st))) return rc;
-    if ((rc = pack_conv_weight_T(d->cell2_w, wb + bp.cell2T, nullptr, 4 * C2, C1, C2, 3, 2, st))) return rc;
-    if ((rc = pack_conv_weight_T(d->lu2_w, wb + bp.lu2T, nullptr, C2, C2 / 2, 0, 1, 1, st))) return rc;
-    if ((rc = pack_conv_weight_T(d->dem2_w, wb + bp.dem2T, nullptr, C2, C2 / 2, 0, 1, 1, st))) return rc;
-    for (int k = 0; k < d->n_blocks; ++k)
-        if ((rc = pack_conv_weight_T(d->up_w[k], wb + bp.upT[k], nullptr, 4 * C2, C2, 0, 3, 2, st))) return rc;
+    {
+        PackBatch batch;
+        pack_batch_begin(&batch);
+        auto packT = [&](const float* w, size_t at, int cout, int c0, int c1, int ks, int ksplit) {
+            return pack_batch_add(&batch, pack_job_T(w, wb + at, nullptr, cout, c0, c1, ks, ksplit), st);
+        };
+        if ((rc = packT(d->post2_w, bp.post2T, 1, 32, 0, 3, 1))) return rc;
+        if ((rc = packT(d->post0_w, bp.post0T, 32, C2, 0, 3, 1))) return rc;
+        if ((rc = packT(d->cell1_w, bp.cell1T, 4 * C1, C1, C1, 3, 1))) return rc;
+        if ((rc = packT(d->cell2_w, bp.cell2T, 4 * C2, C1, C2, 3, 2))) return rc;
+        if ((rc = packT(d->lu2_w, bp.lu2T, C2, C2 / 2, 0, 1, 1))) return rc;
+        if ((rc = packT(d->dem2_w, bp.dem2T, C2, C2 / 2, 0, 1, 1))) return rc;
+        for (int k = 0; k < d->n_blocks; ++k)
+            if ((rc = packT(d->up_w[k], bp.upT[k], 4 * C2, C2, 0, 3, 2))) return rc;
+        if ((rc = pack_batch_flush(&batch, st))) return rc;
+    }
 
     // ---- output convs -------------------------------------------------------------------------
     const PlcTensor gout = tens(g->grad_out, (long long)T * ohw * 4, ohw * 4);   // n = t*B + b -> grad_out[b][t]
@@ -337,7 +391,7 @@ extern "C" int plc_generator_rollout_bwd(const plc_rollout_desc* d, const plc_ro
         ConvArgs in = conv_args(oH, oW, B);
         in.src0 = tens(wf + fp.p0, 4 * ohw * 16, (long long)B * 4 * ohw * 16);
         if ((rc = launch_wgrad<4, 0, 1, 3, STAGE_CB8>(in, tens(wb + bp.d_out8, ohw * 16, (long long)B * ohw * 16), 1, NI,
-                                                      slab, bp.slab_bytes, g->post2_w, g->post2_b, 1, 32, 0, st)))
+                                                      slab, g->post2_w, g->post2_b, 1, 32, 0, st)))
             return rc;
         ConvArgs a = conv_args(oH, oW, B);
         a.src0 = gout;
@@ -353,7 +407,7 @@ extern "C" int plc_generator_rollout_bwd(const plc_rollout_desc* d, const plc_ro
         in.src0 = tens(wf + fp.fin, fimg, (long long)B * fimg);
         in.gate = tens(wf + fp.gate, fimg, 0);
         if ((rc = launch_wgrad<4, 0, 1, 3, STAGE_CB8_GATED>(in, tens(wb + bp.d_pre0, 4 * ohw * 16, (long long)B * 4 * ohw * 16),
-                                                            4, NI, slab, bp.slab_bytes, g->post0_w, g->post0_b, 32, C2, 0, st)))
+                                                            4, NI, slab, g->post0_w, g->post0_b, 32, C2, 0, st)))
             return rc;
         a = conv_args(oH, oW, B);
         a.src0 = tens(wb + bp.d_pre0, 4 * ohw * 16, (long long)B * 4 * ohw * 16);
@@ -392,7 +446,7 @@ extern "C" int plc_generator_rollout_bwd(const plc_rollout_desc* d, const plc_ro
             // 1x1 conv (C2/2 -> C2): weight gradient, then data gradient masked by the ReLU of the 3x3 conv
             ConvArgs in = conv_args(oH, oW, B);
             in.src0 = tens(wf + q.mid, mcb * ohw * 16, 0);
-            if ((rc = launch_wgrad<2, 0, 1, 1, STAGE_CB8>(in, tens(wb + q.d_pre, fimg, 0), C2 / 8, B, slab, bp.slab_bytes,
+            if ((rc = launch_wgrad<2, 0, 1, 1, STAGE_CB8>(in, tens(wb + q.d_pre, fimg, 0), C2 / 8, B, slab,
                                                           q.g2w, q.g2b, C2, C2 / 2, 0, st)))
                 return rc;
             ConvArgs a = conv_args(oH, oW, B);
@@ -409,10 +463,10 @@ extern "C" int plc_generator_rollout_bwd(const plc_rollout_desc* d, const plc_ro
             in.src0 = tens(wf + q.hr, cdiv(q.cin, 8) * ohw * 16, 0);
             if (q.cin <= 8)
                 rc = launch_wgrad<1, 0, 1, 3, STAGE_CB8>(in, tens(wb + q.d_mid, mcb * ohw * 16, 0), mcb, B, slab,
-                                                         bp.slab_bytes, q.g0w, q.g0b, C2 / 2, q.cin, 0, st);
+                                                         q.g0w, q.g0b, C2 / 2, q.cin, 0, st);
             else
                 rc = launch_wgrad<2, 0, 1, 3, STAGE_CB8>(in, tens(wb + q.d_mid, mcb * ohw * 16, 0), mcb, B, slab,
-                                                         bp.slab_bytes, q.g0w, q.g0b, C2 / 2, q.cin, 0, st);
+                                                         q.g0w, q.g0b, C2 / 2, q.cin, 0, st);
             if (rc) return rc;
         }
     }
@@ -445,7 +499,7 @@ extern "C" int plc_generator_rollout_bwd(const plc_rollout_desc* d, const plc_ro
         ConvArgs in = conv_args(kh, kw, NI);
         in.src0 = tens(in_k, (C2 / 8) * khw * 16, 0);
         if ((rc = launch_wgrad<4, 0, 4, 3, STAGE_CB8>(in, tens(wb + bp.d_conv[k], (4 * C2 / 8) * khw * 16, 0), 4 * C2 / 8,
-                                                      NI, slab, bp.slab_bytes, g->up_w[k], g->up_b[k], 4 * C2, C2, 0, st)))
+                                                      NI, slab, g->up_w[k], g->up_b[k], 4 * C2, C2, 0, st)))
             return rc;
         ConvArgs a = conv_args(kh, kw, NI);
         a.src0 = tens(wb + bp.d_conv[k], (4 * C2 / 8) * khw * 16, 0);
@@ -498,17 +552,18 @@ extern "C" int plc_generator_rollout_bwd(const plc_rollout_desc* d, const plc_ro
         in.row_tab = d->row_tab;
         in.col_tab = d->col_tab;
         if ((rc = launch_wgrad<1, 0, 1, 3, STAGE_COORD>(in, tens(wb + bp.d_pre_init, fp.img1, (long long)B * fp.img1),
-                                                        C1 / 8, NI, slab, bp.slab_bytes, g->init_w, g->init_b, C1, 3, 0, st)))
+                                                        C1 / 8, NI, slab, g->init_w, g->init_b, C1, 3, 0, st)))
             return rc;
     }
     // ---- gate-conv weight gradients, batched over all T*B frames -------------------------------
     if ((rc = cell_wgrad(wb + bp.dz2, tens(wf + fp.h1s + s1, fp.img1, (long long)B * fp.img1),
-                         tens(wf + fp.h2s, fp.img2, (long long)B * fp.img2), B, NI, slab, bp.slab_bytes, g->cell2_w,
+                         tens(wf + fp.h2s, fp.img2, (long long)B * fp.img2), B, NI, slab, g->cell2_w,
                          g->cell2_b, C1, C2, H, W, st)))
         return rc;
     if ((rc = cell_wgrad(wb + bp.dz1, tens(wf + fp.xs, fp.img1, (long long)B * fp.img1),
-                         tens(wf + fp.h1s, fp.img1, (long long)B * fp.img1), B, NI, slab, bp.slab_bytes, g->cell1_w,
+                         tens(wf + fp.h1s, fp.img1, (long long)B * fp.img1), B, NI, slab, g->cell1_w,
                          g->cell1_b, C1, C1, H, W, st)))
         return rc;
-    return PLC_OK;
+    // ---- every conv's slabs -> parameter gradients, one launch ----------------------------------
+    return arena_flush(&arena, st);
 }

@@ -67,6 +67,7 @@ struct ConvArgs {
     int cout;            // EPI_F32_NCHW: number of fp32 channels stored
     int act;             // EPI_ACT_CB8 / EPI_F32_NCHW activation
     int save_gates;      // EPI_LSTM: also store i,f,o,g (bf16) for the backward pass
+    int zero_state;      // EPI_LSTM: the recurrent inputs (src1 = h, c_in) are all zero and are not read
     int mul_mode;        // EPI_ACT_CB8 with `mul`: MUL_PRODUCT (v *= m) or MUL_RELU_MASK (v = m > 0 ? v : 0)
     PlcTensor src0;      // CB8 bf16, first NCB0 channel blocks   (STAGE_COORD / STAGE_F32_1CH: fp32 plane)
     PlcTensor src1;      // CB8 bf16, next NCB1 channel blocks
@@ -381,7 +382,7 @@ __device__ __forceinline__ void plc_conv_body(const ConvArgs& a, const int block
                 const int ly = r / LW;
                 const int lx = r - ly * LW;
                 const int gy = y0 - PAD + ly, gx = x0 - PAD + lx;
-                const bool ok = (cb < NCB) & (gy >= 0) & (gy < H) & (gx >= 0) & (gx < W);
+                const bool ok = (cb < NCB) & (gy >= 0) & (gy < H) & (gx >= 0) & (gx < W) & !(a.zero_state && cb >= NCB0);
                 const char* base = (cb < NCB0) ? (s0 + cb * plane_b) : (s1 + (cb - NCB0) * plane_b);
                 const long long poff = cb * plane_b + ((long long)gy * W + gx) * 16;
                 const char* src = ok ? base + ((long long)gy * W + gx) * 16 : (const char*)&plc_zero16;
@@ -559,7 +560,8 @@ __device__ __forceinline__ void plc_conv_body(const ConvArgs& a, const int block
                 if constexpr (DO_MMA) {
 #pragma unroll
                     for (int r = 0; r < NREP; ++r)
-                        cnew[r] = *(const float4*)(cin_base + (long long)(y0 + row0 + r) * W * 32 + lane_c);
+                        cnew[r] = a.zero_state ? make_float4(0.f, 0.f, 0.f, 0.f)
+                                               : *(const float4*)(cin_base + (long long)(y0 + row0 + r) * W * 32 + lane_c);
                     bf16x8_t fr[NF];
                     const char* fbase = lds + row0 * LW * 16 + (px * 16 + half * PLANE * 16);
                     auto frag = [&](auto fc) {
@@ -629,7 +631,7 @@ __device__ __forceinline__ void plc_conv_body(const ConvArgs& a, const int block
             cpre[r] = make_float4(0.f, 0.f, 0.f, 0.f);
             if constexpr (IS_LSTM) {
                 const int gy = y0 + row0 + r, gx = x0 + px;
-                if (gy < H && gx < W)
+                if (gy < H && gx < W && !a.zero_state)
                     cpre[r] = *(const float4*)(plc_img(a.c_in, n, a.n_in) +
                                                ((long long)mt * H * W + (long long)gy * W + gx) * 32 + half * 16);
             }

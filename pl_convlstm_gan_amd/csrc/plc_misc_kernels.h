@@ -29,16 +29,29 @@ __device__ __forceinline__ int plc_padded_to_concat(int cb, int j, int c0, int c
 // transposed != 0 (data gradient): rows = channels of the block-padded concat [src0 | src1]
 //      (plain order), K channels = the cout output channels, taps flipped:
 //      W'[ci][o][dy][dx] = w[o][ci][ks-1-dy][ks-1-dx].
-__global__ void plc_pack_weight_kernel(const float* __restrict__ w, const float* __restrict__ bias,
-                                       unsigned short* __restrict__ wpk, float* __restrict__ bpk,
-                                       int cout, int c0, int c1, int ks, int mode, int n_mt, int nks_w,
-                                       int ch_per_gate, int transposed, int ksplit) {
+// One conv's packing job; `block` of `n_blocks` (256 threads each) share it grid-stride fashion.
+struct PackJob {
+    const float* w;
+    const float* bias;
+    unsigned short* wpk;
+    float* bpk;
+    int cout, c0, c1, ks, mode, n_mt, nks_w, ch_per_gate, transposed, ksplit;
+    int first_block, n_blocks;      // position inside a multi-job launch
+};
+
+__device__ __forceinline__ void plc_pack_weight_body(const PackJob& jb, int block, int n_blocks) {
+    const float* __restrict__ w = jb.w;
+    const float* __restrict__ bias = jb.bias;
+    unsigned short* __restrict__ wpk = jb.wpk;
+    float* __restrict__ bpk = jb.bpk;
+    const int cout = jb.cout, c0 = jb.c0, c1 = jb.c1, ks = jb.ks, mode = jb.mode, n_mt = jb.n_mt, nks_w = jb.nks_w;
+    const int ch_per_gate = jb.ch_per_gate, transposed = jb.transposed, ksplit = jb.ksplit;
     const int ncb_k = transposed ? (cout + 7) / 8 : (c0 + 7) / 8 + (c1 + 7) / 8;
     const int ncbw = ncb_k / ksplit;
     const int taps = ks * ks;
     const long long total = (long long)n_mt * ksplit * nks_w * 64 * 8;
-    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
-         idx += (long long)gridDim.x * blockDim.x) {
+    for (long long idx = block * (long long)blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)n_blocks * blockDim.x) {
         const int j = idx & 7;
         const int lane = (idx >> 3) & 63;
         long long rest = idx >> 9;
@@ -67,7 +80,7 @@ __global__ void plc_pack_weight_kernel(const float* __restrict__ w, const float*
         wpk[idx] = f2bf(v);
     }
     if (bpk) {
-        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_mt * 32; i += gridDim.x * blockDim.x) {
+        for (int i = block * blockDim.x + threadIdx.x; i < n_mt * 32; i += n_blocks * blockDim.x) {
             float b = 0.0f;
             if (!transposed && bias) {
                 const int o = plc_row_to_cout(mode, i >> 5, i & 31, ch_per_gate);
@@ -76,6 +89,21 @@ __global__ void plc_pack_weight_kernel(const float* __restrict__ w, const float*
             bpk[i] = b;
         }
     }
+}
+
+__global__ void plc_pack_weight_kernel(const PackJob jb) { plc_pack_weight_body(jb, blockIdx.x, gridDim.x); }
+
+// Every conv of a rollout in ONE launch (the weights change every optimizer step, so they are
+// re-packed per call; one launch instead of ten to twenty tiny ones).
+constexpr int PACK_MAX_JOBS = 24;
+struct PackTable {
+    PackJob job[PACK_MAX_JOBS];
+    int n;
+};
+__global__ void plc_pack_multi_kernel(const PackTable tb) {
+    int j = 0;
+    while (j + 1 < tb.n && (int)blockIdx.x >= tb.job[j + 1].first_block) ++j;
+    plc_pack_weight_body(tb.job[j], blockIdx.x - tb.job[j].first_block, tb.job[j].n_blocks);
 }
 
 // NCHW fp32 -> CB8 bf16 (channels padded with zeros to a multiple of 8).

@@ -205,16 +205,27 @@ __global__ __launch_bounds__(512, 2) void plc_wgrad_kernel(const WgradArgs a) {
 }
 
 // Sum the per-workgroup slabs (fixed order) and scatter into dW [cout][c0+c1][ks][ks], db [cout].
-__global__ void plc_wgrad_finalize_kernel(const float* __restrict__ slab, int n_slabs, int rows_pad, int cols_pad,
-                                          float* __restrict__ dw, float* __restrict__ db, int cout, int c0, int c1,
-                                          int ks, int ncb) {
+struct FinalizeJob {
+    const float* slab;
+    float* dw;
+    float* db;
+    int n_slabs, rows_pad, cols_pad, cout, c0, c1, ks, ncb;
+    int first_block, n_blocks;      // position inside a multi-job launch
+};
+
+__device__ __forceinline__ void plc_wgrad_finalize_body(const FinalizeJob& jb, int block, int n_blocks,
+                                                        float (*part)[33]) {
     // 256 threads = 32 consecutive output elements x 8 slab lanes; lane q sums slabs q, q+8, ...
     // and the 8 partial sums are combined in a fixed order through LDS.
-    __shared__ float part[8][33];
+    const float* __restrict__ slab = jb.slab;
+    float* __restrict__ dw = jb.dw;
+    float* __restrict__ db = jb.db;
+    const int n_slabs = jb.n_slabs, rows_pad = jb.rows_pad, cols_pad = jb.cols_pad, cout = jb.cout;
+    const int c0 = jb.c0, c1 = jb.c1, ks = jb.ks, ncb = jb.ncb;
     const int taps = ks * ks, ncbp = (ncb + 1) / 2;
     const long long total = (long long)cout * cols_pad;
     const int el = threadIdx.x & 31, q = threadIdx.x >> 5;
-    for (long long base = (long long)blockIdx.x * 32; base < total; base += (long long)gridDim.x * 32) {
+    for (long long base = (long long)block * 32; base < total; base += (long long)n_blocks * 32) {
         const long long idx = base + el;
         float s = 0.0f;
         if (idx < total) {
@@ -250,4 +261,22 @@ __global__ void plc_wgrad_finalize_kernel(const float* __restrict__ slab, int n_
         }
         __syncthreads();
     }
+}
+
+__global__ void plc_wgrad_finalize_kernel(const FinalizeJob jb) {
+    __shared__ float part[8][33];
+    plc_wgrad_finalize_body(jb, blockIdx.x, gridDim.x, part);
+}
+
+// The slabs of every conv of a backward pass, reduced in ONE launch at its end.
+constexpr int FINALIZE_MAX_JOBS = 24;
+struct FinalizeTable {
+    FinalizeJob job[FINALIZE_MAX_JOBS];
+    int n;
+};
+__global__ void plc_wgrad_finalize_multi_kernel(const FinalizeTable tb) {
+    __shared__ float part[8][33];
+    int j = 0;
+    while (j + 1 < tb.n && (int)blockIdx.x >= tb.job[j + 1].first_block) ++j;
+    plc_wgrad_finalize_body(tb.job[j], blockIdx.x - tb.job[j].first_block, tb.job[j].n_blocks, part);
 }
