@@ -66,7 +66,8 @@ static int arena_flush(SlabArena* ar, hipStream_t st) {
 // `in` carries H, W, n_in and the staging tensors of the conv input; dz has mcb_valid channel blocks.
 template <int NCB0, int NCB1, int MT, int KS, int STAGE>
 static int launch_wgrad(ConvArgs in, PlcTensor dz, int mcb_valid, int n_img, SlabArena* ar,
-                        float* dw, float* db, int cout, int c0, int c1, hipStream_t st) {
+                        float* dw, float* db, int cout, int c0, int c1, hipStream_t st,
+                        const PlcTensor* dz_mask = nullptr) {
     using G = WgradGeom<NCB0 + NCB1, MT, KS>;
     const size_t need = wgrad_slab_bytes<NCB0, NCB1, MT, KS>();
     if (ar->used + need > ar->size || ar->tb.n == FINALIZE_MAX_JOBS) {
@@ -82,6 +83,7 @@ static int launch_wgrad(ConvArgs in, PlcTensor dz, int mcb_valid, int n_img, Sla
     a.in.tiles_x = cdiv(in.W, 32);
     a.in.tiles_y = cdiv(in.H, WG_TH);
     a.dz = dz;
+    if (dz_mask) a.dz_mask = *dz_mask;
     a.mcb_valid = mcb_valid;
     a.n_tiles = n_img * a.in.tiles_x * a.in.tiles_y;
     a.slab = slab;
@@ -264,7 +266,7 @@ struct BwdPlan {
     size_t d_out8, d_pre0, d_feat, d_pre, d_lu_pre, d_dem_pre, d_lu_mid, d_dem_mid;
     size_t d_conv[8], d_in[8];
     size_t d_mid, d_up;     // (size_t)-1 when the corresponding bilinear resize is absent
-    size_t dz1, dz2, dcat1, dcat2, dc1, dc2, d_pre_init, slab, slab_bytes, total;
+    size_t dz1, dz2, dcat1, dcat2, dc1, dc2, slab, slab_bytes, total;
 };
 
 static size_t max_sz(size_t a, size_t b) { return a > b ? a : b; }
@@ -306,7 +308,6 @@ static int bwd_plan(const plc_rollout_desc* d, const RolloutPlan& fp, BwdPlan* p
     p->dcat2 = take((size_t)2 * B * ((C1 + C2) / 8) * hw * 16);
     p->dc1 = take((size_t)2 * B * (C1 / 8) * hw * 32);
     p->dc2 = take((size_t)2 * B * (C2 / 8) * hw * 32);
-    p->d_pre_init = take((size_t)NI * (C1 / 8) * hw * 16);
     // slab arena: the slabs of every weight-gradient launch of the pass, so one reduction at the end serves all
     size_t sb = wgrad_slab_bytes<2, 4, 4, 3>() + wgrad_slab_bytes<2, 2, 2, 3>();            // cell 2, cell 1
     sb += 2 * wgrad_slab_bytes<4, 0, 1, 3>();                                                // post0, post2
@@ -541,18 +542,15 @@ extern "C" int plc_generator_rollout_bwd(const plc_rollout_desc* d, const plc_ro
             return rc;
         if ((rc = cell_dgrad(dz1_t, wb + bp.cell1T, bpk0, dcat1_t, B, C1, C1, H, W, st))) return rc;
     }
-    // ---- stem: gradient through the ReLU, then the weight gradient ----------------------------
-    hipLaunchKernelGGL(plc_relu_mask_kernel, dim3(ew_grid((long long)NI * (C1 / 8) * hw)), dim3(256), 0, st,
-                       view(wb + bp.dcat1, cat1), view(wf + fp.xs, fp.img1), wb + bp.d_pre_init, (long long)fp.img1, NI,
-                       C1 / 8, hw);
-    PLC_HIP(hipGetLastError());
+    // ---- stem: weight gradient; the gradient through its ReLU is a mask applied while loading dz ----
     {
         ConvArgs in = conv_args(H, W, B);
         in.src0 = tens(d->rain, (long long)T * hw * 4, hw * 4);
         in.row_tab = d->row_tab;
         in.col_tab = d->col_tab;
-        if ((rc = launch_wgrad<1, 0, 1, 3, STAGE_COORD>(in, tens(wb + bp.d_pre_init, fp.img1, (long long)B * fp.img1),
-                                                        C1 / 8, NI, slab, g->init_w, g->init_b, C1, 3, 0, st)))
+        const PlcTensor relu_of = tens(wf + fp.xs, fp.img1, (long long)B * fp.img1);      // stem output
+        if ((rc = launch_wgrad<1, 0, 1, 3, STAGE_COORD>(in, tens(wb + bp.dcat1, cat1, (long long)B * cat1), C1 / 8, NI,
+                                                        slab, g->init_w, g->init_b, C1, 3, 0, st, &relu_of)))
             return rc;
     }
     // ---- gate-conv weight gradients, batched over all T*B frames -------------------------------

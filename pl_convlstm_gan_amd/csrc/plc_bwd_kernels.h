@@ -160,22 +160,6 @@ __global__ void plc_gate_bwd_kernel(const GateBwdArgs a) {
     }
 }
 
-// out = mask > 0 ? d : 0 over N images of ncb blocks; d / mask / out are CB8 bf16 views.
-__global__ void plc_relu_mask_kernel(Cb8View d, Cb8View mask, char* out, long long out_img, int N, int ncb,
-                                     long long hw) {
-    const long long img = (long long)ncb * hw;
-    const long long total = (long long)N * img;
-    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
-         idx += (long long)gridDim.x * blockDim.x) {
-        const long long n = idx / img, u = idx % img;
-        const F8 g = ld_bf8(d.p + n * d.img + u * 16), m = ld_bf8(mask.p + n * mask.img + u * 16);
-        F8 r;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) r.v[j] = m.v[j] > 0.0f ? g.v[j] : 0.0f;
-        st_bf8(out + n * out_img + u * 16, r);
-    }
-}
-
 // Backward of ReLU(PixelShuffle(2)(conv)):  d_conv[4c + 2i + j][y][x] = y_up[c][2y+i][2x+j] > 0 ?
 // d_up[c][2y+i][2x+j] : 0.   d_up / y_up: CB8 bf16 [N][C/8][2H][2W]; d_conv: CB8 bf16 [N][4C/8][H][W].
 __global__ void plc_pixel_unshuffle_mask_kernel(const char* __restrict__ d_up, const char* __restrict__ y_up,

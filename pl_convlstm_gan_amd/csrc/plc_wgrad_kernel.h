@@ -28,6 +28,7 @@ typedef __attribute__((__vector_size__(4 * sizeof(short)))) short s16x4_t;
 struct WgradArgs {
     ConvArgs in;       // H, W, tiles_x, tiles_y, n_in and the staging fields (src0, src1, gate, tabs)
     PlcTensor dz;      // CB8 bf16, ceil(cout/8) channel blocks
+    PlcTensor dz_mask; // optional (p may be null): CB8 bf16 like dz; dz counts only where mask > 0 (ReLU backward)
     int mcb_valid;     // channel blocks present in dz
     int n_tiles;       // n_img * tiles_y * tiles_x
     float* slab;       // [gridDim.x][MT*32][NT*32]
@@ -141,8 +142,20 @@ __global__ __launch_bounds__(512, 2) void plc_wgrad_kernel(const WgradArgs a) {
                 const int cb = d / (WG_TH * 32);
                 const int r = d - cb * (WG_TH * 32);
                 const int gy = y0 + (r >> 5), gx = x0 + (r & 31);
-                if (cb < a.mcb_valid && gy < H && gx < W)
-                    v = *(const uint4*)(dzp + (((long long)cb * H + gy) * W + gx) * 16);
+                if (cb < a.mcb_valid && gy < H && gx < W) {
+                    const long long off = (((long long)cb * H + gy) * W + gx) * 16;
+                    v = *(const uint4*)(dzp + off);
+                    if (a.dz_mask.p) {
+                        // bf16 > 0  <=>  sign bit clear and the other 15 bits not all zero
+                        const uint4 mk = *(const uint4*)(plc_img(a.dz_mask, n, a.in.n_in) + off);
+                        auto keep = [](unsigned m) {
+                            const unsigned lo = (m & 0x8000u) == 0 && (m & 0x7fffu) != 0 ? 0x0000ffffu : 0u;
+                            const unsigned hi = (m & 0x80000000u) == 0 && (m & 0x7fff0000u) != 0 ? 0xffff0000u : 0u;
+                            return lo | hi;
+                        };
+                        v.x &= keep(mk.x); v.y &= keep(mk.y); v.z &= keep(mk.z); v.w &= keep(mk.w);
+                    }
+                }
             }
             pf[k] = v;
         }
