@@ -188,7 +188,7 @@ def main():
         dbg("timed region done")
         dt = time.perf_counter() - t0
         if world > 1:
-            tt = torch.tensor([dt], device=device, dtype=torch.float64)
+            tt = torch.tensor([dt], device=device if backend == "nccl" else "cpu", dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt = float(tt.item())
         assert torch.isfinite(last.detach()).all()
@@ -233,6 +233,7 @@ def main():
             res["cpu_baseline"] = cpu_baseline(args.mode, B, T, H, W, s, params)
         print(json.dumps(res), flush=True)
     if world > 1:
+        barrier()        # rank 0 is still timing the roofline kernel / printing: leave together
         dist.destroy_process_group()
 
 

@@ -41,10 +41,23 @@ def _world(group=None) -> int:
     return dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
 
 
+def _all_reduce(t: torch.Tensor, op, group=None) -> torch.Tensor:
+    """dist.all_reduce in place.  With the gloo backend and a GPU tensor the reduction goes through
+    a host copy (gloo's own GPU path deadlocks when several ranks share one GPU, which is how the
+    multi-process control flow is rehearsed on a one-GPU box); RCCL reduces the GPU tensor directly."""
+    if t.is_cuda and dist.get_backend(group) == "gloo":
+        host = t.detach().cpu()
+        dist.all_reduce(host, op=op, group=group)
+        t.copy_(host)
+    else:
+        dist.all_reduce(t, op=op, group=group)
+    return t
+
+
 def all_reduce_mean_(flat: torch.Tensor, group=None) -> torch.Tensor:
     w = _world(group)
     if w > 1:
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        _all_reduce(flat, dist.ReduceOp.SUM, group)
         flat.mul_(1.0 / w)
     return flat
 
@@ -53,7 +66,7 @@ def any_rank_true(flag: torch.Tensor, group=None) -> bool:
     """Collective OR of a 0-dim bool/float tensor (host sync, as the reference's isnan check)."""
     f = flag.to(torch.float32).reshape(1)
     if _world(group) > 1:
-        dist.all_reduce(f, op=dist.ReduceOp.MAX, group=group)
+        _all_reduce(f, dist.ReduceOp.MAX, group)
     return bool(f.item() > 0)
 
 

@@ -24,6 +24,33 @@ CASES = [
 ]
 
 
+def test_inference_rollout_captures_into_a_hip_graph(gpu):
+    """The library calls are plain stream work (no allocation, no synchronisation), so a caller can
+    capture the whole inference rollout with torch.cuda.graph; the replay is bit-identical."""
+    from pl_convlstm_gan_amd import Generator
+    torch.manual_seed(1)
+    m = Generator(hidden_dims=[16, 32], lu_channels=5, scale_factor=2).to(gpu)
+    rain = torch.rand(2, 3, 1, 24, 40, device=gpu)
+    dem = torch.rand(2, 1, 48, 80, device=gpu)
+    lu = torch.rand(2, 5, 48, 80, device=gpu)
+    with torch.no_grad():
+        ref = m(rain, dem, lu).clone()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side), torch.no_grad():
+        m(rain, dem, lu)
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.no_grad(), torch.cuda.graph(graph):
+        out = m(rain, dem, lu)
+    rain.mul_(0.5)                       # new input values in the captured buffers
+    with torch.no_grad():
+        ref2 = m(rain, dem, lu).clone()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref2) and not torch.equal(ref2, ref)
+
+
 def relmax(a, b):
     return float((a - b).abs().max()) / max(float(b.abs().max()), 1e-20)
 
