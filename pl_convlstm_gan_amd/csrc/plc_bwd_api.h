@@ -20,9 +20,12 @@ __global__ void plc_plane_to_cb8_kernel(PlcTensor src, int n_in, int N, long lon
 // weight gradient launcher
 // ---------------------------------------------------------------------------------------------
 // Persistent workgroups per launch: one per CU when the LDS double buffer fills the CU, two when
-// two fit.  (The kernel is bound by LDS read bandwidth -- both MFMA operands come from LDS through
-// transposing reads, 1.2 KB per MFMA for cell 2 -- not by global latency: staging the tiles by
-// LDS-DMA two tiles ahead was measured and changed nothing.)
+// two fit.  Measured on the cell-2 launch (1.07 GB of dz + halo tiles per pass, ~325 us = 3.3 TB/s):
+// staging the tiles by LDS-DMA two tiles ahead, issuing all of a tile's prefetch loads together
+// instead of one after another, and sharing each B fragment between the KS vertical taps (40 %
+// fewer transposing LDS reads, 7 % more MFMAs) each left its time unchanged, so neither global
+// latency nor the LDS read count is what bounds it; the parallel prefetch pays only where a tile
+// takes many loads per thread (the gated staging: 174 -> 136 us).
 template <int NCB0, int NCB1, int MT, int KS>
 static constexpr int wgrad_max_blocks() {
     return WgradGeom<NCB0 + NCB1, MT, KS>::LDS_BYTES <= 80 * 1024 ? 512 : 256;
@@ -69,6 +72,8 @@ static int launch_wgrad(ConvArgs in, PlcTensor dz, int mcb_valid, int n_img, Sla
                         float* dw, float* db, int cout, int c0, int c1, hipStream_t st,
                         const PlcTensor* dz_mask = nullptr) {
     using G = WgradGeom<NCB0 + NCB1, MT, KS>;
+    if (dz_mask && STAGE == STAGE_CB8)
+        return plc_fail(PLC_EUNSUPPORTED, "wgrad: the plain CB8 staging does not load a dz mask");
     const size_t need = wgrad_slab_bytes<NCB0, NCB1, MT, KS>();
     if (ar->used + need > ar->size || ar->tb.n == FINALIZE_MAX_JOBS) {
         int rc = arena_flush(ar, st);

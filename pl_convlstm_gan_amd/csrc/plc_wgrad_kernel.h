@@ -36,6 +36,20 @@ struct WgradArgs {
 
 constexpr int WG_TH = 4;
 
+// eight bf16 1.0: the "keep everything" ReLU mask of launches without one
+__device__ const uint4 plc_ones16 = {0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};
+
+// Loads through a selected pointer, pinned to the global address space (a select between a tensor
+// address and a __device__ constant otherwise degrades to a flat load, which also ties up lgkmcnt).
+#define PLC_AS1 __attribute__((address_space(1)))
+typedef unsigned int plc_u32x4 __attribute__((ext_vector_type(4)));     // uint4 is a class: its copy goes through a generic reference
+__device__ __forceinline__ uint4 plc_gload16(const char* p) {
+    const plc_u32x4 v = *(const PLC_AS1 plc_u32x4*)p;
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ float plc_gload4(const char* p) { return *(const PLC_AS1 float*)p; }
+
+
 template <int NCB, int MT, int KS>
 struct WgradGeom {
     static constexpr int TAPS = KS * KS;
@@ -118,7 +132,18 @@ __global__ __launch_bounds__(512, 2) void plc_wgrad_kernel(const WgradArgs a) {
     const int tiles_per_img = a.in.tiles_x * a.in.tiles_y;
 
     // ---- tile loader: global -> registers, registers -> LDS ---------------------------------
-    uint4 pf[G::NPF];
+    // Two phases.  load_tile only SELECTS per-lane addresses (a real one, or a 16-byte constant for
+    // lanes outside the image) and then loads unconditionally, so no load sits in a divergent
+    // branch and all NPF (+ secondary) loads of a tile are in flight together while the current
+    // tile is contracted.  store_tile forms the LDS units from the landed registers: the gated
+    // product, the coord-conv unit, the ReLU-masked dz.
+    static_assert(STAGE == STAGE_CB8 || STAGE == STAGE_CB8_GATED || STAGE == STAGE_COORD, "unsupported staging");
+    constexpr bool HAS2 = STAGE != STAGE_CB8;       // secondary 16-byte load: gate (input part), ReLU mask (dz part)
+    constexpr int NPF_IN = (G::IN_UNITS + 511) / 512;             // prefetch slots that hold input-part lanes
+    constexpr int NPF2 = HAS2 ? G::NPF : 1;
+    constexpr int NPFC = STAGE == STAGE_COORD ? NPF_IN : 1;
+    uint4 pf[G::NPF], pf2[NPF2];
+    float pf_rain[NPFC], pf_row[NPFC], pf_col[NPFC];
     auto load_tile = [&](int t) {
         const int n = t / tiles_per_img;
         const int rem = t - n * tiles_per_img;
@@ -128,43 +153,89 @@ __global__ __launch_bounds__(512, 2) void plc_wgrad_kernel(const WgradArgs a) {
         const char* s1 = NCB1 > 0 ? plc_img(a.in.src1, n, a.in.n_in) : nullptr;
         const char* gt = STAGE == STAGE_CB8_GATED ? plc_img(a.in.gate, n, a.in.n_in) : nullptr;
         const char* dzp = plc_img(a.dz, n, a.in.n_in);
+        const bool has_mask = HAS2 && a.dz_mask.p != nullptr;
+        const char* mkp = has_mask ? plc_img(a.dz_mask, n, a.in.n_in) : nullptr;
+        const char* const z16 = (const char*)&plc_zero16;
+        const char* const o16 = (const char*)&plc_ones16;
+        const long long plane_b = (long long)H * W * 16;
 #pragma unroll
         for (int k = 0; k < G::NPF; ++k) {
             const int u = tid + k * 512;
-            uint4 v = make_uint4(0, 0, 0, 0);
+            const char* p1 = z16;
+            const char* p2 = o16;
+            const char* pr = z16;
+            const char* prow = z16;
+            const char* pcol = z16;
             if (u < G::IN_UNITS) {
                 const int cb = u / G::PLANE;
                 const int r = u - cb * G::PLANE;
                 const int ly = r / G::LW, lx = r - ly * G::LW;
-                v = plc_stage_unit<STAGE, NCB0>(a.in, s0, s1, gt, cb, y0 - G::PAD + ly, x0 - G::PAD + lx, H, W);
+                const int gy = y0 - G::PAD + ly, gx = x0 - G::PAD + lx;
+                const bool ok = (gy >= 0) & (gy < H) & (gx >= 0) & (gx < W);
+                const long long pix = (long long)gy * W + gx;
+                if (STAGE == STAGE_COORD) {
+                    pr = ok ? s0 + pix * 4 : z16;
+                    prow = ok ? (const char*)(a.in.row_tab + gy) : z16;
+                    pcol = ok ? (const char*)(a.in.col_tab + gx) : z16;
+                } else {
+                    const char* base = (NCB1 == 0 || cb < NCB0) ? s0 + cb * plane_b : s1 + (cb - NCB0) * plane_b;
+                    p1 = ok ? base + pix * 16 : z16;
+                    if (STAGE == STAGE_CB8_GATED) p2 = ok ? gt + cb * plane_b + pix * 16 : z16;
+                }
             } else if (u < G::IN_UNITS + G::DZ_UNITS) {
                 const int d = u - G::IN_UNITS;
                 const int cb = d / (WG_TH * 32);
                 const int r = d - cb * (WG_TH * 32);
                 const int gy = y0 + (r >> 5), gx = x0 + (r & 31);
-                if (cb < a.mcb_valid && gy < H && gx < W) {
-                    const long long off = (((long long)cb * H + gy) * W + gx) * 16;
-                    v = *(const uint4*)(dzp + off);
-                    if (a.dz_mask.p) {
-                        // bf16 > 0  <=>  sign bit clear and the other 15 bits not all zero
-                        const uint4 mk = *(const uint4*)(plc_img(a.dz_mask, n, a.in.n_in) + off);
-                        auto keep = [](unsigned m) {
-                            const unsigned lo = (m & 0x8000u) == 0 && (m & 0x7fffu) != 0 ? 0x0000ffffu : 0u;
-                            const unsigned hi = (m & 0x80000000u) == 0 && (m & 0x7fff0000u) != 0 ? 0xffff0000u : 0u;
-                            return lo | hi;
-                        };
-                        v.x &= keep(mk.x); v.y &= keep(mk.y); v.z &= keep(mk.z); v.w &= keep(mk.w);
-                    }
+                const bool ok = (cb < a.mcb_valid) & (gy < H) & (gx < W);
+                const long long off = (((long long)cb * H + gy) * W + gx) * 16;
+                p1 = ok ? dzp + off : z16;
+                if (HAS2) p2 = (ok & has_mask) ? mkp + off : o16;
+            }
+            pf[k] = plc_gload16(p1);
+            if constexpr (HAS2) pf2[k] = plc_gload16(p2);
+            if constexpr (STAGE == STAGE_COORD) {
+                if (k < NPF_IN) {
+                    pf_rain[k] = plc_gload4(pr);
+                    pf_row[k] = plc_gload4(prow);
+                    pf_col[k] = plc_gload4(pcol);
                 }
             }
-            pf[k] = v;
         }
     };
     auto store_tile = [&](int buf) {
 #pragma unroll
         for (int k = 0; k < G::NPF; ++k) {
             const int u = tid + k * 512;
-            if (u < G::IN_UNITS + G::DZ_UNITS) smem[buf * G::BUF_UNITS + u] = pf[k];
+            uint4 v = pf[k];
+            if constexpr (STAGE == STAGE_CB8_GATED) {
+                if (u < G::IN_UNITS) {
+                    // src0 * gate, rounded to bf16 (the conv's own gated staging forms the same product)
+                    const uint4 f = pf[k], g = pf2[k];
+                    const float4 f0 = unpack_bf4(make_uint2(f.x, f.y)), f1 = unpack_bf4(make_uint2(f.z, f.w));
+                    const float4 g0 = unpack_bf4(make_uint2(g.x, g.y)), g1 = unpack_bf4(make_uint2(g.z, g.w));
+                    const uint2 lo = pack_bf4(f0.x * g0.x, f0.y * g0.y, f0.z * g0.z, f0.w * g0.w);
+                    const uint2 hi = pack_bf4(f1.x * g1.x, f1.y * g1.y, f1.z * g1.z, f1.w * g1.w);
+                    v = make_uint4(lo.x, lo.y, hi.x, hi.y);
+                }
+            }
+            if constexpr (STAGE == STAGE_COORD) {
+                if (k < NPF_IN && u < G::IN_UNITS)      // channels (rain, row coordinate, column coordinate, 0 ...)
+                    v = make_uint4(pack_bf2(pf_rain[k], pf_row[k]), pack_bf2(pf_col[k], 0.0f), 0u, 0u);
+            }
+            if constexpr (HAS2) {
+                if (u >= G::IN_UNITS) {
+                    // dz counts where mask > 0;  bf16 > 0  <=>  sign bit clear and the other 15 bits not all zero
+                    auto keep = [](unsigned m) {
+                        const unsigned lo = (m & 0x8000u) == 0 && (m & 0x7fffu) != 0 ? 0x0000ffffu : 0u;
+                        const unsigned hi = (m & 0x80000000u) == 0 && (m & 0x7fff0000u) != 0 ? 0xffff0000u : 0u;
+                        return lo | hi;
+                    };
+                    const uint4 mk = pf2[k];
+                    v.x &= keep(mk.x); v.y &= keep(mk.y); v.z &= keep(mk.z); v.w &= keep(mk.w);
+                }
+            }
+            if (u < G::IN_UNITS + G::DZ_UNITS) smem[buf * G::BUF_UNITS + u] = v;
         }
     };
 
