@@ -35,6 +35,7 @@ struct WgradArgs {
 };
 
 constexpr int WG_TH = 4;
+constexpr int WG_PF_DEPTH = 4;     // B fragments requested ahead of the MFMA that consumes them (6 measured no better)
 
 // eight bf16 1.0: the "keep everything" ReLU mask of launches without one
 __device__ const uint4 plc_ones16 = {0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};
@@ -252,20 +253,50 @@ __global__ __launch_bounds__(512, 2) void plc_wgrad_kernel(const WgradArgs a) {
         const int tn = t + gridDim.x;
         if (tn < a.n_tiles) load_tile(tn);            // next tile's loads fly during the MFMAs below
         const int boff = buf * G::BUF_UNITS * 16;
-#pragma unroll
-        for (int ks = 0; ks < WG_TH * 2; ++ks) {
+        // The tile's MFMAs as one flat software pipeline: MFMA j = (k-step j / NT_W, column tile
+        // j % NT_W).  Its B fragment is requested DEPTH MFMAs earlier (ring of DEPTH + 1 fragments), its
+        // A fragment together with the first B of its k-step.  Left to itself the scheduler sinks
+        // each transposing read next to its use and every MFMA then waits out an LDS round trip
+        // (matrix pipe 44 % busy with two waves per SIMD); sched_barrier pins the order written
+        // here, the compiler still derives the exact lgkmcnt waits.
+        constexpr int TOTAL = WG_TH * 2 * G::NT_W;
+        constexpr int DEPTH = TOTAL < WG_PF_DEPTH ? TOTAL : WG_PF_DEPTH;
+        constexpr int BR = DEPTH + 1, AR = DEPTH / G::NT_W + 2;
+        bf16x8_t bq[BR], aq[AR];
+        auto frag = [&](int addr) {
+            const s16x4_t v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((PLC_AS3 s16x4_t*)(lds + boff + addr));
+            const s16x4_t v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((PLC_AS3 s16x4_t*)(lds + boff + addr + 64));
+            return __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7));
+        };
+        auto issue = [&](int jj) {      // the fragment reads MFMA jj needs (jj is a constant after unrolling)
+            const int ks = jj / G::NT_W, i = jj % G::NT_W;
             const int row = ks >> 1, xk = (ks & 1) * 16;
-            const int offa = (row * 32 + xk) * 16;
-            const int offb = (row * G::LW + xk) * 16;
-            const s16x4_t a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((PLC_AS3 s16x4_t*)(lds + boff + a_addr + offa));
-            const s16x4_t a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((PLC_AS3 s16x4_t*)(lds + boff + a_addr + offa + 64));
-            const bf16x8_t af = __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7));
+            if (i == 0) aq[ks % AR] = frag(a_addr + (row * 32 + xk) * 16);
+            bq[jj % BR] = frag(b_addr[i] + (row * G::LW + xk) * 16);
+        };
+        // Only where ONE workgroup fits a CU (two waves per SIMD): with two workgroups the four
+        // waves per SIMD already cover the LDS latency and the pinned order was measured slower
+        // (cell 1: 144 -> 172 us), so those instantiations keep the compiler's own schedule.
+        if constexpr (G::LDS_BYTES > 80 * 1024) {
 #pragma unroll
-            for (int i = 0; i < G::NT_W; ++i) {
-                const s16x4_t b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((PLC_AS3 s16x4_t*)(lds + boff + b_addr[i] + offb));
-                const s16x4_t b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((PLC_AS3 s16x4_t*)(lds + boff + b_addr[i] + offb + 64));
-                const bf16x8_t bfr = __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7));
-                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, acc[i], 0, 0, 0);
+            for (int jj = 0; jj < DEPTH; ++jj) issue(jj);
+#pragma unroll
+            for (int j = 0; j < TOTAL; ++j) {
+                if (j + DEPTH < TOTAL) issue(j + DEPTH);
+                __builtin_amdgcn_sched_barrier(0);
+                acc[j % G::NT_W] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[(j / G::NT_W) % AR], bq[j % BR],
+                                                                           acc[j % G::NT_W], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < WG_TH * 2; ++ks) {
+                const int row = ks >> 1, xk = (ks & 1) * 16;
+                const bf16x8_t af = frag(a_addr + (row * 32 + xk) * 16);
+#pragma unroll
+                for (int i = 0; i < G::NT_W; ++i)
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, frag(b_addr[i] + (row * G::LW + xk) * 16),
+                                                                     acc[i], 0, 0, 0);
             }
         }
         if (tn < a.n_tiles) store_tile(buf ^ 1);
