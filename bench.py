@@ -37,6 +37,10 @@ FLOP_PER_PX_FWD = 171104          # algorithmic forward FLOPs per output pixel p
 CELL2_FLOP_PER_PX = 2 * 55296     # cell-2 gate conv: (16+32)*9*128 MACs per pixel
 CELL2_BYTES_PER_PX = 416          # x 32 + h 64 + c 128 read, h' 64 + c' 128 written (bf16 h, fp32 c)
 PEAK_BF16 = 2.5e15                # dense bf16 MFMA peak of MI355X, FLOP/s
+PEAK_HBM = 8.0e12                 # HBM3E peak of MI355X, B/s
+# pointwise LSTM backward, per 8-channel unit of one pixel: two dh (bf16) 32 + dc' (fp32) 32 + c (fp32) 32
+# + gates i,f,o,g (bf16) 64 read; dz (bf16) 64 + dc (fp32) 32 written
+PW_BWD_BYTES_PER_UNIT = 256
 N_STATIONS = 35
 
 
@@ -80,6 +84,42 @@ def time_cell2_kernel(B, H, W, device, iters=50):
     e0.record()
     for _ in range(iters):
         run()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e-3 / iters
+
+
+def time_pointwise_bwd_kernel(B, H, W, device, Ch=32, iters=50):
+    """Average duration of the kernel that takes the largest share of a train step (the pointwise
+    LSTM backward, here at cell 2's width with two incoming dh and dc', as in every step but the
+    last), measured with events on the stream it is launched on."""
+    from pl_convlstm_gan_amd import _lib, ops
+    L = _lib.lib()
+    ncb = Ch // 8
+    bf = lambda *shape: (torch.randn(*shape, device=device) * 0.5).to(torch.bfloat16).view(torch.int16)
+    # four operand sets used in rotation (> 1 GB in total), so that no launch finds its inputs in the
+    # 256 MB Infinity Cache: in the step the gates and cell states were written long before
+    sets = []
+    for _ in range(4):
+        gates = torch.rand(B, 4 * ncb, H, W, 8, device=device).to(torch.bfloat16).view(torch.int16)
+        c_prev = torch.randn(B, ncb, H, W, 8, device=device)
+        sets.append((bf(B, ncb, H, W, 8), bf(B, ncb, H, W, 8), torch.randn(B, ncb, H, W, 8, device=device), gates,
+                     c_prev, torch.empty_like(gates), torch.empty_like(c_prev)))
+    img = ncb * H * W * 16
+    st = ops._stream()
+
+    def run(k):
+        dh0, dh1, dc_in, gates, c_prev, dz, dc = sets[k % len(sets)]
+        _lib.check(L.plc_lstm_pointwise_bwd(dh0.data_ptr(), img, dh1.data_ptr(), img, None, 0, dc_in.data_ptr(),
+                                            gates.data_ptr(), c_prev.data_ptr(), dz.data_ptr(), dc.data_ptr(),
+                                            B, Ch, H, W, st), "pointwise_bwd")
+    for k in range(5):
+        run(k)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for k in range(iters):
+        run(k)
     e1.record()
     torch.cuda.synchronize()
     return e0.elapsed_time(e1) * 1e-3 / iters
@@ -222,12 +262,28 @@ def main():
         tj = os.path.join(ROOT, "profiles", "r1_cell2_traffic.json")
         if os.path.exists(tj) and args.config == "c3":
             traffic = json.load(open(tj)).get("hbm_bytes_per_launch")
-        res["roofline"] = {"bound": "mfma", "kernel": "plc_conv_mfma_kernel<2,4,4,3,CB8,LSTM> (cell-2 gate conv + LSTM epilogue)",
-                           "achieved": flops / tk / 1e12, "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
-                           "frac": flops / tk / PEAK_BF16, "traffic": traffic,
-                           "launch_us": tk * 1e6, "flop_per_launch": flops,
-                           "alg_bytes_per_launch": CELL2_BYTES_PER_PX * B * H * W,
-                           "hbm_frac": CELL2_BYTES_PER_PX * B * H * W / tk / 8e12}
+        mfma_roof = {"bound": "mfma", "kernel": "plc_conv_mfma_kernel<2,4,4,3,CB8,LSTM> (cell-2 gate conv + LSTM epilogue)",
+                     "achieved": flops / tk / 1e12, "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
+                     "frac": flops / tk / PEAK_BF16, "traffic": traffic,
+                     "launch_us": tk * 1e6, "flop_per_launch": flops,
+                     "alg_bytes_per_launch": CELL2_BYTES_PER_PX * B * H * W,
+                     "hbm_frac": CELL2_BYTES_PER_PX * B * H * W / tk / PEAK_HBM}
+        if args.mode == "train":
+            # the kernel with the largest share of a train step is the HBM-bound pointwise LSTM
+            # backward (2T launches); the cell-2 conv, top kernel of the forward, follows as roofline_mfma
+            tp = time_pointwise_bwd_kernel(B, H, W, device)
+            pw_bytes = PW_BWD_BYTES_PER_UNIT * B * 4 * H * W          # cell 2: 4 channel blocks per pixel
+            pw_traffic = None
+            pj = os.path.join(ROOT, "profiles", "r1_pointwise_bwd_traffic.json")
+            if os.path.exists(pj) and args.config == "c3":
+                pw_traffic = json.load(open(pj)).get("hbm_bytes_per_launch")
+            res["roofline"] = {"bound": "hbm", "kernel": "plc_lstm_pointwise_bwd_kernel (cell 2, one timestep)",
+                               "achieved": pw_bytes / tp / 1e9, "peak": PEAK_HBM / 1e9, "unit": "GB/s",
+                               "frac": pw_bytes / tp / PEAK_HBM, "traffic": pw_traffic,
+                               "launch_us": tp * 1e6, "alg_bytes_per_launch": pw_bytes}
+            res["roofline_mfma"] = mfma_roof
+        else:
+            res["roofline"] = mfma_roof
         if not args.no_cpu_baseline and world == 1:
             params = {k: v.detach().cpu() for k, v in model.state_dict().items()}
             res["cpu_baseline"] = cpu_baseline(args.mode, B, T, H, W, s, params)

@@ -17,7 +17,7 @@ EXPORTS = (
     "plc_packed_weight_bytes", "plc_packed_bias_bytes", "plc_pack_conv_weight",
     "plc_convlstm_cell_fwd_cb8", "plc_convlstm_cell_workspace_bytes", "plc_convlstm_cell_fwd",
     "plc_generator_workspace_bytes", "plc_generator_rollout_fwd", "plc_generator_workspace_offset",
-    "plc_convlstm_cell_bwd_workspace_bytes", "plc_convlstm_cell_bwd",
+    "plc_convlstm_cell_bwd_workspace_bytes", "plc_convlstm_cell_bwd", "plc_lstm_pointwise_bwd",
     "plc_generator_bwd_workspace_bytes", "plc_generator_rollout_bwd",
     "plc_combined_loss_workspace_bytes", "plc_combined_loss",
     "plc_clip_adam_workspace_bytes", "plc_clip_adam_step",
@@ -121,6 +121,8 @@ def lib():
     L.plc_convlstm_cell_bwd_workspace_bytes.argtypes = [i, i, i, i, i]
     L.plc_convlstm_cell_bwd.restype = i
     L.plc_convlstm_cell_bwd.argtypes = [p] * 13 + [sz, i, i, i, i, i, p]
+    L.plc_lstm_pointwise_bwd.restype = i
+    L.plc_lstm_pointwise_bwd.argtypes = [p, C.c_longlong, p, C.c_longlong, p, C.c_longlong, p, p, p, p, p, i, i, i, i, p]
     L.plc_generator_bwd_workspace_bytes.restype = sz
     L.plc_generator_bwd_workspace_bytes.argtypes = [C.POINTER(RolloutDesc)]
     L.plc_generator_rollout_bwd.restype = i

@@ -193,6 +193,17 @@ static CellBwdWs cell_bwd_ws(int B, int Cin, int Ch, int H, int W) {
     return s;
 }
 
+extern "C" int plc_lstm_pointwise_bwd(const void* dh0, long long dh0_image_bytes, const void* dh1,
+                                      long long dh1_image_bytes, const void* dh2, long long dh2_image_bytes,
+                                      const float* dc_next, const void* gates, const float* c_prev, void* dz,
+                                      float* dc, int B, int Ch, int H, int W, void* stream) {
+    PLC_REQUIRE(gates && c_prev && dz && dc, "plc_lstm_pointwise_bwd: null pointer");
+    PLC_REQUIRE(B > 0 && H > 0 && W > 0, "plc_lstm_pointwise_bwd: non-positive size");
+    PLC_REQUIRE(Ch > 0 && Ch % 8 == 0, "plc_lstm_pointwise_bwd: Ch must be a positive multiple of 8");
+    return lstm_pointwise_bwd(view(dh0, dh0_image_bytes), view(dh1, dh1_image_bytes), view(dh2, dh2_image_bytes),
+                              dc_next, gates, c_prev, nullptr, dz, dc, B, Ch, H, W, (hipStream_t)stream);
+}
+
 extern "C" size_t plc_convlstm_cell_bwd_workspace_bytes(int B, int Cin, int Ch, int H, int W) {
     if (B <= 0 || Cin <= 0 || Ch <= 0 || H <= 0 || W <= 0) return 0;
     return cell_bwd_ws(B, Cin, Ch, H, W).total;
