@@ -65,9 +65,15 @@ struct WgradGeom {
     static constexpr int WN = 8 / MT;                   // N groups of waves
     static constexpr int NT_W = (NT + WN - 1) / WN;
     static constexpr int IN_UNITS = NCB * PLANE;
-    static constexpr int DZ_UNITS = MCB * WG_TH * 32;
+    static constexpr int DZ_UNITS = MCB * WG_TH * 32;   // dz units of a tile (what the loader fetches)
+    // In LDS each dz channel block is padded by 4 units: the four blocks a 32-lane group reads for
+    // an A fragment then start 64 B apart mod 256 and tile the bank row; at the natural stride
+    // (2048 B = 0 mod 256) they collide 4-way, which made up most of the kernel's bank conflicts.
+    static constexpr int DZ_CB = WG_TH * 32 + 4;
+    static constexpr int DZ_LDS_UNITS = MCB * DZ_CB;
     static constexpr int CONST_UNITS = 128;             // 2 KiB: covers every k-step offset of a tile
-    static constexpr int BUF_UNITS = IN_UNITS + DZ_UNITS + 2 * CONST_UNITS;   // [in | dz | zeros | ones]
+    static constexpr int CONST_BASE = IN_UNITS + DZ_LDS_UNITS;
+    static constexpr int BUF_UNITS = CONST_BASE + 2 * CONST_UNITS;   // [in | dz | zeros | ones]
     static constexpr int LDS_BYTES = 2 * BUF_UNITS * 16;
     static constexpr int NPF = (IN_UNITS + DZ_UNITS + 511) / 512;
 };
@@ -95,7 +101,7 @@ __global__ __launch_bounds__(512, 2) void plc_wgrad_kernel(const WgradArgs a) {
     for (int i = tid; i < 2 * 2 * G::CONST_UNITS; i += 512) {
         const int buf = i / (2 * G::CONST_UNITS), r = i % (2 * G::CONST_UNITS);
         const unsigned v = r < G::CONST_UNITS ? 0u : 0x3F803F80u;
-        smem[buf * G::BUF_UNITS + G::IN_UNITS + G::DZ_UNITS + r] = make_uint4(v, v, v, v);
+        smem[buf * G::BUF_UNITS + G::CONST_BASE + r] = make_uint4(v, v, v, v);
     }
 
     // per-lane byte addresses (buffer 0, k-step 0) of the two transposed reads of each fragment
@@ -103,7 +109,7 @@ __global__ __launch_bounds__(512, 2) void plc_wgrad_kernel(const WgradArgs a) {
     int a_addr;   // A: dz block, channel block 4m + 2*(g16&1) + (p>>1)
     {
         const int cb = 4 * m + 2 * (g16 & 1) + (p >> 1);
-        a_addr = (G::IN_UNITS + cb * WG_TH * 32) * 16 + pix_off;
+        a_addr = (G::IN_UNITS + cb * G::DZ_CB) * 16 + pix_off;
     }
     int b_addr[G::NT_W];
 #pragma unroll
@@ -115,11 +121,11 @@ __global__ __launch_bounds__(512, 2) void plc_wgrad_kernel(const WgradArgs a) {
             const int tap = grp / G::NCBP, cbp = grp % G::NCBP;
             const int cb = 2 * cbp + (p >> 1);
             if (cb < NCB) addr = ((cb * G::LH + tap / KS) * G::LW + tap % KS) * 16 + pix_off;
-            else addr = (G::IN_UNITS + G::DZ_UNITS) * 16 + (p & 1) * 8;                         // zeros
+            else addr = G::CONST_BASE * 16 + (p & 1) * 8;                                       // zeros
         } else if (grp == G::TAPS * G::NCBP) {
-            addr = (G::IN_UNITS + G::DZ_UNITS + G::CONST_UNITS) * 16 + (p & 1) * 8;             // ones (bias)
+            addr = (G::CONST_BASE + G::CONST_UNITS) * 16 + (p & 1) * 8;                         // ones (bias)
         } else {
-            addr = (G::IN_UNITS + G::DZ_UNITS) * 16 + (p & 1) * 8;                              // zeros
+            addr = G::CONST_BASE * 16 + (p & 1) * 8;                                            // zeros
         }
         b_addr[i] = addr;
     }
@@ -236,7 +242,9 @@ __global__ __launch_bounds__(512, 2) void plc_wgrad_kernel(const WgradArgs a) {
                     v.x &= keep(mk.x); v.y &= keep(mk.y); v.z &= keep(mk.z); v.w &= keep(mk.w);
                 }
             }
-            if (u < G::IN_UNITS + G::DZ_UNITS) smem[buf * G::BUF_UNITS + u] = v;
+            // input part at its unit index; dz part with each channel block padded to DZ_CB units
+            const int dst = u < G::IN_UNITS ? u : u + (u - G::IN_UNITS) / (WG_TH * 32) * (G::DZ_CB - WG_TH * 32);
+            if (u < G::IN_UNITS + G::DZ_UNITS) smem[buf * G::BUF_UNITS + dst] = v;
         }
     };
 
