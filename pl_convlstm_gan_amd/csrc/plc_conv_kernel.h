@@ -245,6 +245,37 @@ constexpr int plc_conv_lds_bytes() {
 // source of out-of-image units for the LDS-DMA staging
 __device__ const uint4 plc_zero16 = {0u, 0u, 0u, 0u};
 
+// Loads through a selected pointer, pinned to the global address space (a select between a tensor
+// address and a __device__ constant otherwise degrades to a flat load, which also ties up lgkmcnt).
+#define PLC_AS1 __attribute__((address_space(1)))
+typedef unsigned int plc_u32x4 __attribute__((ext_vector_type(4)));     // uint4 is a class: its copy goes through a generic reference
+typedef float plc_f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 plc_gload16(const char* p) {
+    const plc_u32x4 v = *(const PLC_AS1 plc_u32x4*)p;
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ float4 plc_gload_f4(const char* p) {
+    const plc_f32x4 v = *(const PLC_AS1 plc_f32x4*)p;
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ float plc_gload4(const char* p) { return *(const PLC_AS1 float*)p; }
+
+// s_waitcnt vmcnt(n) for a wave-uniform run-time n (the instruction takes an immediate): waits until
+// at most n of this wave's vector-memory operations are outstanding.  Values above the table wait
+// for a smaller count, which is only stricter.
+__device__ __forceinline__ void plc_wait_vmcnt_le(int n) {
+#define PLC_VMCNT_CASE(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
+    switch (n) {
+        PLC_VMCNT_CASE(1) PLC_VMCNT_CASE(2) PLC_VMCNT_CASE(3) PLC_VMCNT_CASE(4) PLC_VMCNT_CASE(5) PLC_VMCNT_CASE(6)
+        PLC_VMCNT_CASE(7) PLC_VMCNT_CASE(8) PLC_VMCNT_CASE(9) PLC_VMCNT_CASE(10) PLC_VMCNT_CASE(11) PLC_VMCNT_CASE(12)
+        PLC_VMCNT_CASE(13) PLC_VMCNT_CASE(14) PLC_VMCNT_CASE(15) PLC_VMCNT_CASE(16)
+        default:
+            if (n > 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+#undef PLC_VMCNT_CASE
+}
+
 // Waves per SIMD to compile for: three (three workgroups per CU) for the light convs, whose time is
 // load/store latency rather than MFMA issue; two when the stationary weights need the registers.
 template <int NCB, int KS, int KSPLIT, int NMT, int EPI>
@@ -260,6 +291,17 @@ template <int NKS>
 __device__ __forceinline__ void plc_load_weights(bf16x8_t (&wf)[NKS], const uint4* src) {
 #pragma unroll
     for (int s = 0; s < NKS; ++s) wf[s] = __builtin_bit_cast(bf16x8_t, src[s * 64]);
+}
+
+// The same loads issued as inline asm: the compiler keeps no count of them, so the caller must wait
+// (s_waitcnt vmcnt) itself before the first use of wf.
+template <int NKS>
+__device__ __forceinline__ void plc_load_weights_asm(bf16x8_t (&wf)[NKS], const uint4* src) {
+#pragma unroll
+    for (int s = 0; s < NKS; ++s) {
+        const uint4* p = src + s * 64;
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(wf[s]) : "v"(p) : "memory");
+    }
 }
 
 // Whether a workgroup of this instantiation walks several tiles.  The LSTM convs (register file and
@@ -321,16 +363,31 @@ __device__ __forceinline__ void plc_conv_body(const ConvArgs& a, const int block
 
     PLC_STAMP(0);
     PLC_STAMP_HWID();
+    constexpr bool IS_LSTM = (EPI == EPI_LSTM || EPI == EPI_LSTM_SAVE);
+    constexpr bool PIPE = IS_LSTM && KSPLIT == 1 && (NCBW % 2 == 0);
+    constexpr bool SPLIT_STAGE = PIPE && STAGE == STAGE_CB8 && PASSES > 1 && NMT % 2 == 0;   // two-phase wait on the halo tile
+
     // ---- weights: stationary A fragments, fetched once per workgroup ------------------------
     bf16x8_t wf[NKS];
     const uint4* const wsrc = a.wpk + ((long long)(mt * KSPLIT + ks) * NKS) * 64 + lane;
     // (requesting the halo tile before the weights was measured 1.5 us slower per cell launch)
-    plc_load_weights<NKS>(wf, wsrc);
-    // this workgroup's bias rows (row order of the packed M tiles) for the pipelined LSTM path
-    if (tid < NMT * 32) ((float*)(tile + TILE_UNITS + RED_UNITS))[tid] = a.bpk[block_y * NMT * 32 + tid];
-
-    constexpr bool IS_LSTM = (EPI == EPI_LSTM || EPI == EPI_LSTM_SAVE);
-    constexpr bool PIPE = IS_LSTM && KSPLIT == 1 && (NCBW % 2 == 0);
+    if constexpr (SPLIT_STAGE) {
+        // Two-phase staged tile: weights, bias and tile pieces are requested back to back and the
+        // compiler must not count any of them, or it drains ALL of them (it cannot bound the
+        // number of tile pieces) before the first MFMA reads a weight register.  The weights are
+        // fetched by asm loads and the bias goes straight to LDS by DMA; both are older than every
+        // tile piece, so the wait for the early pieces (loads retire in order) covers them.
+        plc_load_weights_asm<NKS>(wf, wsrc);
+        const int wave_b = __builtin_amdgcn_readfirstlane(wave);
+        if (wave_b < NMT / 2)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.bpk + block_y * NMT * 32 + tid),
+                                             (__attribute__((address_space(3))) void*)((float*)(tile + TILE_UNITS + RED_UNITS) + wave_b * 64),
+                                             4, 0, 0);
+    } else {
+        plc_load_weights<NKS>(wf, wsrc);
+        // this workgroup's bias rows (row order of the packed M tiles) for the pipelined LSTM path
+        if (tid < NMT * 32) ((float*)(tile + TILE_UNITS + RED_UNITS))[tid] = a.bpk[block_y * NMT * 32 + tid];
+    }
     float4 bv[4];   // bias of this lane's 16 rows (accumulator initial value of the generic pass loop)
     auto load_bias = [&]() {
         const float4* bias4 = (const float4*)a.bpk + mt * 8;
@@ -375,7 +432,25 @@ __device__ __forceinline__ void plc_conv_body(const ConvArgs& a, const int block
             constexpr int NCHUNK = TILE_UNITS / 64;
             const long long plane_b = (long long)H * W * 16;
             const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+            // Pipelined LSTM path: the pieces holding rows that pass 0 reads are requested first and
+            // only they are awaited before it; the rest of the tile lands while pass 0 runs (the
+            // loads retire in order, so "all but the n_late youngest" is exactly the early set).
+            auto early_piece = [&](int ch) {      // wave-uniform
+                const int u0 = ch * 64, r0 = u0 % PLANE;
+                if (r0 + 63 >= PLANE) return true;                  // runs into the next plane's first rows
+                const int lya = r0 / LW, lyb = (r0 + 63) / LW;
+                bool hit = false;
+#pragma unroll
+                for (int g = 0; g < RG; ++g) hit |= (lya <= g * RPW + NREP + KS - 2) & (lyb >= g * RPW);
+                return hit;
+            };
+            int n_late = 0;
+            for (int phase = 0; phase < (SPLIT_STAGE ? 2 : 1); ++phase)
             for (int ch = wave_u; ch < NCHUNK; ch += 4) {
+                if (SPLIT_STAGE) {
+                    if (early_piece(ch) != (phase == 0)) continue;
+                    n_late += phase;
+                }
                 const int u = ch * 64 + lane;
                 const int cb = u / PLANE;
                 const int r = u - cb * PLANE;
@@ -395,7 +470,8 @@ __device__ __forceinline__ void plc_conv_body(const ConvArgs& a, const int block
                         (__attribute__((address_space(3))) void*)(tile + TILE_UNITS + RED_UNITS + BIAS_UNITS + ch * 64), 16, 0, 0);
                 }
             }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if constexpr (SPLIT_STAGE) plc_wait_vmcnt_le(n_late);
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if constexpr (STAGE == STAGE_CB8_GATED) {
                 // a wave multiplies the pieces it fetched itself, so no barrier is needed in between
                 const uint4* gtile = tile + TILE_UNITS + RED_UNITS + BIAS_UNITS;
@@ -434,7 +510,18 @@ __device__ __forceinline__ void plc_conv_body(const ConvArgs& a, const int block
         }
     }
     PLC_STAMP(2);
-    __syncthreads();
+    if constexpr (SPLIT_STAGE) {
+        // Bare barrier: __syncthreads() carries a workgroup fence, for which the compiler drains
+        // every outstanding vector-memory operation, i.e. also the late pieces still in flight.
+        // What must be ordered here is LDS only: this wave's early pieces have landed (vmcnt wait
+        // above) and its bias write has retired (lgkmcnt); the clobbers keep the compiler from
+        // moving LDS accesses across.
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    } else {
+        __syncthreads();
+    }
     PLC_STAMP(3);
 
     const char* lds = (const char*)tile;
@@ -479,6 +566,26 @@ __device__ __forceinline__ void plc_conv_body(const ConvArgs& a, const int block
                         acc[r][4 * g + 3] = b.w;
                     }
                 }
+            };
+            // The same ahead of pass 0 of a two-phase staged tile: asm reads, for the reason given
+            // at that pass's fragment reads.
+            auto init_acc_early = [&](f32x16_t (&acc)[NREP]) {
+                typedef float f32x4_t __attribute__((ext_vector_type(4)));
+                f32x4_t b[4];
+                const unsigned b32 = (unsigned)(size_t)(const __attribute__((address_space(3))) char*)bias_l;
+                asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:32\n\t"
+                             "ds_read_b128 %2, %4 offset:64\n\tds_read_b128 %3, %4 offset:96\n\t"
+                             "s_waitcnt lgkmcnt(0)"
+                             : "=&v"(b[0]), "=&v"(b[1]), "=&v"(b[2]), "=&v"(b[3]) : "v"(b32) : "memory");
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int r = 0; r < NREP; ++r) {
+                        acc[r][4 * g + 0] = b[g].x;
+                        acc[r][4 * g + 1] = b[g].y;
+                        acc[r][4 * g + 2] = b[g].z;
+                        acc[r][4 * g + 3] = b[g].w;
+                    }
             };
             auto run = [&](auto do_mma, auto do_epi, f32x16_t (&acc)[NREP], float4 (&cnew)[NREP],
                            f32x16_t (&prv)[NREP], float4 (&cold)[NREP], int pass) {
@@ -559,20 +666,43 @@ __device__ __forceinline__ void plc_conv_body(const ConvArgs& a, const int block
                 };
                 if constexpr (DO_MMA) {
 #pragma unroll
-                    for (int r = 0; r < NREP; ++r)
-                        cnew[r] = a.zero_state ? make_float4(0.f, 0.f, 0.f, 0.f)
-                                               : *(const float4*)(cin_base + (long long)(y0 + row0 + r) * W * 32 + lane_c);
+                    for (int r = 0; r < NREP; ++r)   // the POINTER is selected, so the load is unconditional and
+                                                     // nothing waits for it before its first use one pass later
+                        cnew[r] = plc_gload_f4(a.zero_state ? (const char*)&plc_zero16
+                                                            : cin_base + (long long)(y0 + row0 + r) * W * 32 + lane_c);
                     bf16x8_t fr[NF];
                     const char* fbase = lds + row0 * LW * 16 + (px * 16 + half * PLANE * 16);
+                    // Pass 0 of a two-phase staged tile runs while the late pieces of the tile are
+                    // still landing.  The compiler waits vmcnt(0) before any LDS read it can see
+                    // while an LDS-DMA write is in flight (it cannot tell the rows apart), so this
+                    // pass issues its fragment reads as inline asm and places the lgkmcnt waits
+                    // itself: LDS reads return in order, so before the MFMAs on fragment f at most
+                    // the younger reads (f+1 .. f+DEPTH) may be outstanding.  The wait names fr[f]
+                    // as an in/out operand, which keeps the MFMAs that consume it behind the wait.
+                    constexpr bool ASM_READS = SPLIT_STAGE && !DO_EPI;
+                    const unsigned fbase32 = (unsigned)(size_t)(const __attribute__((address_space(3))) char*)fbase;
                     auto frag = [&](auto fc) {
                         constexpr int f = decltype(fc)::value;
                         constexpr int rho = f / (KS * NCBP), cbp = (f % (KS * NCBP)) / KS, dx = f % KS;
-                        fr[f] = *(const bf16x8_t*)(fbase + ((rho * LW + dx) + cbp * 2 * PLANE) * 16);
+                        constexpr int off = ((rho * LW + dx) + cbp * 2 * PLANE) * 16;
+                        bf16x8_t& dst = fr[f];              // (asm operands alone do not capture in a generic lambda)
+                        const unsigned base32 = fbase32;
+                        if constexpr (ASM_READS) {
+                            static_assert(off < 65536, "DS instruction offsets are 16 bits");
+                            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(base32), "n"(off) : "memory");
+                        } else {
+                            dst = *(const bf16x8_t*)(fbase + off);
+                        }
                     };
                     plc_static_for<DEPTH>(frag);
                     plc_static_for<NF>([&](auto fc) {
                         constexpr int f = decltype(fc)::value;
                         if constexpr (f + DEPTH < NF) frag(std::integral_constant<int, f + DEPTH>{});
+                        if constexpr (ASM_READS) {
+                            constexpr int younger = (NF - 1 - f) < DEPTH ? (NF - 1 - f) : DEPTH;
+                            bf16x8_t& cur = fr[f];
+                            asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(cur) : "n"(younger) : "memory");
+                        }
                         constexpr int rho = f / (KS * NCBP), cbp = (f % (KS * NCBP)) / KS, dx = f % KS;
                         plc_static_for<NREP>([&](auto rc) {
                             constexpr int r = decltype(rc)::value, dy = rho - r;
@@ -596,9 +726,18 @@ __device__ __forceinline__ void plc_conv_body(const ConvArgs& a, const int block
             };
             f32x16_t accA[NREP], accB[NREP];
             float4 cA[NREP], cB[NREP];
-            init_acc(accA);
-            init_acc(accB);
+            if constexpr (SPLIT_STAGE) {
+                init_acc_early(accA);
+                init_acc_early(accB);
+            } else {
+                init_acc(accA);
+                init_acc(accB);
+            }
             run(std::true_type{}, std::false_type{}, accA, cA, accB, cB, 0);
+            if constexpr (SPLIT_STAGE) {       // the rest of the tile, requested before pass 0, has landed
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+            }
             PLC_STAMP(4);
 #pragma unroll 1
             for (int pass = 1; pass < PASSES; pass += 2) {
@@ -618,6 +757,10 @@ __device__ __forceinline__ void plc_conv_body(const ConvArgs& a, const int block
     }
 
     if constexpr (PIPE) load_bias();   // (only partly filled tiles of the LSTM convs get here)
+    if constexpr (SPLIT_STAGE) {       // the generic loop reads the whole tile
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
 
     PLC_STAMP(4);
 #pragma unroll 1

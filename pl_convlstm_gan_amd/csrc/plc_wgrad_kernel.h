@@ -40,15 +40,6 @@ constexpr int WG_PF_DEPTH = 4;     // B fragments requested ahead of the MFMA th
 // eight bf16 1.0: the "keep everything" ReLU mask of launches without one
 __device__ const uint4 plc_ones16 = {0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};
 
-// Loads through a selected pointer, pinned to the global address space (a select between a tensor
-// address and a __device__ constant otherwise degrades to a flat load, which also ties up lgkmcnt).
-#define PLC_AS1 __attribute__((address_space(1)))
-typedef unsigned int plc_u32x4 __attribute__((ext_vector_type(4)));     // uint4 is a class: its copy goes through a generic reference
-__device__ __forceinline__ uint4 plc_gload16(const char* p) {
-    const plc_u32x4 v = *(const PLC_AS1 plc_u32x4*)p;
-    return make_uint4(v.x, v.y, v.z, v.w);
-}
-__device__ __forceinline__ float plc_gload4(const char* p) { return *(const PLC_AS1 float*)p; }
 
 
 template <int NCB, int MT, int KS>
