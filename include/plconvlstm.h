@@ -168,7 +168,8 @@ int plc_convlstm_cell_bwd(const float* x, const float* h, const float* c,
  *   dh0, dh1, dh2: up to three incoming dL/dh' contributions, CB8 bf16 [B][Ch/8], each with its own
  *                  byte stride between images (a view into a wider tensor is allowed); NULL = absent.
  *   dc_next: dL/dc' (CB8 fp32 [B][Ch/8]) or NULL;  gates: saved i,f,o,g (CB8 bf16 [B][4Ch/8]);
- *   c_prev: c (CB8 fp32).  Writes dz (CB8 bf16 [B][4Ch/8], gate-major) and dc (CB8 fp32).
+ *   c_prev: c (CB8 fp32) or NULL (= zeros, the first timestep of a rollout).
+ *   Writes dz (CB8 bf16 [B][4Ch/8], gate-major) and dc (CB8 fp32).
  * 256 bytes move per 8-channel unit with two dh inputs and dc_next present. */
 int plc_lstm_pointwise_bwd(const void* dh0, long long dh0_image_bytes, const void* dh1, long long dh1_image_bytes,
                            const void* dh2, long long dh2_image_bytes, const float* dc_next, const void* gates,

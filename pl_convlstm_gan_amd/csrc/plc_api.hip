@@ -567,15 +567,10 @@ extern "C" int plc_generator_rollout_fwd(const plc_rollout_desc* d, void* stream
     {
         const size_t s1 = (size_t)B * p.img1, s2 = (size_t)B * p.img2;
         const bool save = d->save_for_backward != 0;
-        // The initial states are zero (generator.py:156-160).  The step-0 cells do not read them
-        // (zero_state); slot 0 of the state arrays is only cleared when the backward pass, whose
-        // batched kernels read every slot, will follow.
-        if (save) {
-            PLC_HIP(hipMemsetAsync(ws + p.h1s, 0, s1, st));
-            PLC_HIP(hipMemsetAsync(ws + p.c1s, 0, s1 * 2, st));
-            PLC_HIP(hipMemsetAsync(ws + p.h2s, 0, s2, st));
-            PLC_HIP(hipMemsetAsync(ws + p.c2s, 0, s2 * 2, st));
-        }
+        // The initial states are zero (generator.py:156-160).  Nothing reads slot 0 of the state
+        // arrays: the step-0 cells take zero_state, the backward's pointwise kernel takes a null
+        // c_prev at t = 0 and its batched weight-gradient launches skip h of the first B images.
+        // So the slot is never written either (no memsets, 75 MB per training forward at c3).
         auto cell1 = [&](int t) {
             ConvArgs a = cell_conv_args(ws + p.xs + t * s1, ws + p.h1s + t * s1, (const float*)(ws + p.c1s + t * s1 * 2),
                                         ws + p.cell1.w, (const float*)(ws + p.cell1.b), ws + p.h1s + (t + 1) * s1,

@@ -150,12 +150,15 @@ static int cell_dgrad(const void* dz, const void* wpkT, const float* bpk0, void*
 }
 static int cell_dgrad_ksplit(int Cin, int Ch) { return (Cin == 16 && Ch == 32) ? 2 : 1; }
 
+// h0_zero: the first n_in images of `h` are the zero initial state and are not read (a rollout
+// does not store them).
 static int cell_wgrad(const void* dz, PlcTensor x, PlcTensor h, int n_in, int n_img, SlabArena* slab,
-                      float* dw, float* db, int Cin, int Ch, int H, int W, hipStream_t st) {
+                      float* dw, float* db, int Cin, int Ch, int H, int W, hipStream_t st, bool h0_zero = false) {
     const long long hw = (long long)H * W;
     ConvArgs in = conv_args(H, W, n_in);
     in.src0 = x;
     in.src1 = h;
+    in.zero_state = h0_zero ? 1 : 0;
     PlcTensor dzt = tens(dz, (4 * Ch / 8) * hw * 16, (long long)n_in * (4 * Ch / 8) * hw * 16);
     if (Cin == 16 && Ch == 16)
         return launch_wgrad<2, 2, 2, 3, STAGE_CB8>(in, dzt, 8, n_img, slab, dw, db, 64, 16, 16, st);
@@ -197,7 +200,7 @@ extern "C" int plc_lstm_pointwise_bwd(const void* dh0, long long dh0_image_bytes
                                       long long dh1_image_bytes, const void* dh2, long long dh2_image_bytes,
                                       const float* dc_next, const void* gates, const float* c_prev, void* dz,
                                       float* dc, int B, int Ch, int H, int W, void* stream) {
-    PLC_REQUIRE(gates && c_prev && dz && dc, "plc_lstm_pointwise_bwd: null pointer");
+    PLC_REQUIRE(gates && dz && dc, "plc_lstm_pointwise_bwd: null pointer");
     PLC_REQUIRE(B > 0 && H > 0 && W > 0, "plc_lstm_pointwise_bwd: non-positive size");
     PLC_REQUIRE(Ch > 0 && Ch % 8 == 0, "plc_lstm_pointwise_bwd: Ch must be a positive multiple of 8");
     return lstm_pointwise_bwd(view(dh0, dh0_image_bytes), view(dh1, dh1_image_bytes), view(dh2, dh2_image_bytes),
@@ -541,7 +544,8 @@ extern "C" int plc_generator_rollout_bwd(const plc_rollout_desc* d, const plc_ro
         if ((rc = lstm_pointwise_bwd(view(cur + (size_t)t * s2, fp.img2),
                                      last ? view(nullptr, 0) : view(dcat2_n + (C1 / 8) * plane, cat2), view(nullptr, 0),
                                      last ? nullptr : dc2_n, wf + fp.gates2 + (size_t)t * s2 * 4,
-                                     wf + fp.c2s + (size_t)t * s2 * 2, wf + fp.c2s + (size_t)(t + 1) * s2 * 2, dz2_t,
+                                     t == 0 ? nullptr : wf + fp.c2s + (size_t)t * s2 * 2,     // c_{-1} = 0 is not stored
+                                     wf + fp.c2s + (size_t)(t + 1) * s2 * 2, dz2_t,
                                      dc2_t, B, C2, H, W, st)))
             return rc;
         if ((rc = cell_dgrad(dz2_t, wb + bp.cell2T, bpk0, dcat2_t, B, C1, C2, H, W, st))) return rc;
@@ -553,7 +557,8 @@ extern "C" int plc_generator_rollout_bwd(const plc_rollout_desc* d, const plc_ro
         char* dz1_t = wb + bp.dz1 + (size_t)t * s1 * 4;
         if ((rc = lstm_pointwise_bwd(view(dcat2_t, cat2), last ? view(nullptr, 0) : view(dcat1_n + (C1 / 8) * plane, cat1),
                                      view(nullptr, 0), last ? nullptr : dc1_n, wf + fp.gates1 + (size_t)t * s1 * 4,
-                                     wf + fp.c1s + (size_t)t * s1 * 2, wf + fp.c1s + (size_t)(t + 1) * s1 * 2, dz1_t,
+                                     t == 0 ? nullptr : wf + fp.c1s + (size_t)t * s1 * 2,
+                                     wf + fp.c1s + (size_t)(t + 1) * s1 * 2, dz1_t,
                                      dc1_t, B, C1, H, W, st)))
             return rc;
         if ((rc = cell_dgrad(dz1_t, wb + bp.cell1T, bpk0, dcat1_t, B, C1, C1, H, W, st))) return rc;
@@ -572,11 +577,11 @@ extern "C" int plc_generator_rollout_bwd(const plc_rollout_desc* d, const plc_ro
     // ---- gate-conv weight gradients, batched over all T*B frames -------------------------------
     if ((rc = cell_wgrad(wb + bp.dz2, tens(wf + fp.h1s + s1, fp.img1, (long long)B * fp.img1),
                          tens(wf + fp.h2s, fp.img2, (long long)B * fp.img2), B, NI, slab, g->cell2_w,
-                         g->cell2_b, C1, C2, H, W, st)))
+                         g->cell2_b, C1, C2, H, W, st, true)))
         return rc;
     if ((rc = cell_wgrad(wb + bp.dz1, tens(wf + fp.xs, fp.img1, (long long)B * fp.img1),
                          tens(wf + fp.h1s, fp.img1, (long long)B * fp.img1), B, NI, slab, g->cell1_w,
-                         g->cell1_b, C1, C1, H, W, st)))
+                         g->cell1_b, C1, C1, H, W, st, true)))
         return rc;
     // ---- every conv's slabs -> parameter gradients, one launch ----------------------------------
     return arena_flush(&arena, st);

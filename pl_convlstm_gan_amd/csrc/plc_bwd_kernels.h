@@ -48,7 +48,7 @@ struct LstmBwdArgs {
     Cb8View dh0, dh1, dh2;         // bf16 CB8 views of ncb blocks
     const char* dc_in;             // fp32 CB8 [B][ncb] or null
     const char* gates;             // bf16 CB8 [B][4*ncb]
-    const char* c_prev;            // fp32 CB8 [B][ncb]
+    const char* c_prev;            // fp32 CB8 [B][ncb] or null (= zeros: the first timestep)
     const char* c_cur;             // fp32 CB8 [B][ncb] (not read: c_t is rebuilt from gates and c_prev)
     char* dz;                      // bf16 CB8 [B][4*ncb]
     char* dc_out;                  // fp32 CB8 [B][ncb]
@@ -82,7 +82,12 @@ __global__ void plc_lstm_pointwise_bwd_kernel(const LstmBwdArgs a) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) dcin.v[j] = 0.0f;
         }
-        const F8 cp = ld_f8(a.c_prev + su * 32);
+        F8 cp;                                   // absent c_prev = the zero initial state
+        if (a.c_prev) cp = ld_f8(a.c_prev + su * 32);
+        else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) cp.v[j] = 0.0f;
+        }
         const F8 gi = ld_bf8(a.gates + (gu + 0 * a.ncb * hw) * 16), gf = ld_bf8(a.gates + (gu + 1 * a.ncb * hw) * 16);
         const F8 go = ld_bf8(a.gates + (gu + 2 * a.ncb * hw) * 16), gg = ld_bf8(a.gates + (gu + 3 * a.ncb * hw) * 16);
         F8 zi, zf, zo, zg, dcp;

@@ -177,7 +177,9 @@ __global__ __launch_bounds__(512, 2) void plc_wgrad_kernel(const WgradArgs a) {
                     pcol = ok ? (const char*)(a.in.col_tab + gx) : z16;
                 } else {
                     const char* base = (NCB1 == 0 || cb < NCB0) ? s0 + cb * plane_b : s1 + (cb - NCB0) * plane_b;
-                    p1 = ok ? base + pix * 16 : z16;
+                    // zero_state: src1 of the first n_in images is the (unstored) zero initial state
+                    const bool skip = NCB1 > 0 && cb >= NCB0 && a.in.zero_state != 0 && n < a.in.n_in;
+                    p1 = (ok & !skip) ? base + pix * 16 : z16;
                     if (STAGE == STAGE_CB8_GATED) p2 = ok ? gt + cb * plane_b + pix * 16 : z16;
                 }
             } else if (u < G::IN_UNITS + G::DZ_UNITS) {

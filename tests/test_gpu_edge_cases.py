@@ -51,6 +51,36 @@ def test_inference_rollout_captures_into_a_hip_graph(gpu):
     assert torch.equal(out, ref2) and not torch.equal(ref2, ref)
 
 
+@pytest.mark.parametrize("shape", [(2, 3, 16, 32, 1), (1, 2, 9, 20, 2)])
+def test_training_step_does_not_depend_on_workspace_contents(gpu, monkeypatch, shape):
+    """The zero initial states are never stored: no kernel may read slot 0 of the state arrays (or
+    any other byte it did not write).  A forward + backward on workspaces pre-filled with 0xFF (NaN
+    in bf16 and fp32) must equal, bit for bit, the same step on zero-filled workspaces."""
+    from pl_convlstm_gan_amd import Generator, ops
+    B, T, H, W, s = shape
+
+    def run(fill):
+        monkeypatch.setattr(ops, "workspace", lambda nbytes, device: torch.full(
+            (max(int(nbytes), 256),), fill, dtype=torch.uint8, device=device))
+        torch.manual_seed(3)
+        m = Generator(hidden_dims=[16, 32], lu_channels=5, scale_factor=s).to(gpu)
+        g = torch.Generator().manual_seed(4)
+        rain = torch.rand(B, T, 1, H, W, generator=g).to(gpu)
+        dem = torch.rand(B, 1, H * s, W * s, generator=g).to(gpu)
+        lu = torch.rand(B, 5, H * s, W * s, generator=g).to(gpu)
+        out = m(rain, dem, lu)
+        (out * out).sum().backward()
+        return out.detach().clone(), {k: p.grad.clone() for k, p in m.named_parameters()}
+
+    out0, g0 = run(0)
+    out1, g1 = run(255)
+    assert torch.isfinite(out1).all()
+    assert torch.equal(out0, out1)
+    for k in g0:
+        assert torch.isfinite(g1[k]).all(), k
+        assert torch.equal(g0[k], g1[k]), k
+
+
 def relmax(a, b):
     return float((a - b).abs().max()) / max(float(b.abs().max()), 1e-20)
 

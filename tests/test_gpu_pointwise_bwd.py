@@ -31,14 +31,18 @@ def bf(x):
     return x.to(torch.bfloat16).float()
 
 
-@pytest.mark.parametrize("B,Ch,H,W,n_dh,with_dc", [(2, 16, 9, 13, 2, True), (1, 32, 16, 40, 3, True),
-                                                   (3, 32, 5, 7, 1, False), (2, 16, 8, 8, 0, True)])
-def test_pointwise_bwd_matches_autograd(gpu, B, Ch, H, W, n_dh, with_dc):
+@pytest.mark.parametrize("B,Ch,H,W,n_dh,with_dc,null_c", [(2, 16, 9, 13, 2, True, False), (1, 32, 16, 40, 3, True, False),
+                                                          (3, 32, 5, 7, 1, False, False), (2, 16, 8, 8, 0, True, False),
+                                                          (2, 32, 6, 10, 2, True, True)])
+def test_pointwise_bwd_matches_autograd(gpu, B, Ch, H, W, n_dh, with_dc, null_c):
+    """null_c: c_prev passed as NULL stands for the zero initial state (first timestep)."""
     from pl_convlstm_gan_amd import _lib
     L = _lib.lib()
     g = torch.Generator().manual_seed(B * 100 + Ch + n_dh)
     z = torch.randn(B, 4 * Ch, H, W, generator=g)
     c_prev = torch.randn(B, Ch, H, W, generator=g)
+    if null_c:
+        c_prev = torch.zeros_like(c_prev)
     dhs = [bf(torch.randn(B, Ch, H, W, generator=g)) for _ in range(n_dh)]
     dc_next = torch.randn(B, Ch, H, W, generator=g) if with_dc else None
     zi, zf, zo, zg = z.split(Ch, dim=1)
@@ -78,7 +82,8 @@ def test_pointwise_bwd_matches_autograd(gpu, B, Ch, H, W, n_dh, with_dc):
     dz8 = torch.empty(B, 4 * Ch // 8, H, W, 8, dtype=torch.int16, device=dev)
     dco8 = torch.empty(B, Ch // 8, H, W, 8, dtype=torch.float32, device=dev)
     rc = L.plc_lstm_pointwise_bwd(views[0][1], views[0][2], views[1][1], views[1][2], views[2][1], views[2][2],
-                                  dc8.data_ptr() if with_dc else None, gates8.data_ptr(), cp8.data_ptr(),
+                                  dc8.data_ptr() if with_dc else None, gates8.data_ptr(),
+                                  None if null_c else cp8.data_ptr(),
                                   dz8.data_ptr(), dco8.data_ptr(), B, Ch, H, W, torch.cuda.current_stream().cuda_stream)
     _lib.check(rc, "plc_lstm_pointwise_bwd")
     torch.cuda.synchronize()
