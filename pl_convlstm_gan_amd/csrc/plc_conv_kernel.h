@@ -154,6 +154,27 @@ __device__ __forceinline__ void plc_epilogue(const ConvArgs& a, const f32x16_t& 
         char* op = plc_img(a.out0, n, a.n_in);
         char* op1 = a.out1.p ? plc_img(a.out1, n, a.n_in) : nullptr;
         const char* mp = a.mul.p ? plc_img(a.mul, n, a.n_in) : nullptr;
+        // The options are wave-uniform, so each test below becomes a scalar branch; taken per element
+        // group that was ~50 branches per stored row (1.4 us per pass of the cell-2 data-gradient
+        // conv).  The common case -- no second output, no multiplier, identity or ReLU -- is decided
+        // once per row and then runs straight-line.
+        if (!op1 && !mp && a.act != ACT_SIGMOID) {
+            char* const o = op + pix * 16 + half * 8;
+            const int n_cb = a.ncb_out - 4 * mt;          // channel blocks of this M tile that are stored
+            auto row = [&](auto relu_c) {
+                constexpr bool RELU = decltype(relu_c)::value;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float v[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = RELU ? fmaxf(acc[4 * g + j], 0.0f) : acc[4 * g + j];
+                    if (g < n_cb) *(uint2*)(o + (long long)(4 * mt + g) * plane_b) = pack_bf4(v[0], v[1], v[2], v[3]);
+                }
+            };
+            if (a.act == ACT_RELU) row(std::true_type{});
+            else row(std::false_type{});
+            return;
+        }
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int cb = 4 * mt + g;
@@ -259,6 +280,18 @@ __device__ __forceinline__ float4 plc_gload_f4(const char* p) {
     return make_float4(v.x, v.y, v.z, v.w);
 }
 __device__ __forceinline__ float plc_gload4(const char* p) { return *(const PLC_AS1 float*)p; }
+
+// Workgroup barrier that orders LDS accesses only.  __syncthreads() carries a workgroup-scope
+// fence, for which the compiler also waits vmcnt(0): after an epilogue that means waiting for the
+// global stores to retire before any wave may go on.  Where the barrier protects nothing but LDS
+// contents (partial-sum exchange, reuse of the tile buffer) this one is enough: the wave's own LDS
+// operations have completed (lgkmcnt) and the clobbers keep the compiler from moving memory
+// accesses across it.
+__device__ __forceinline__ void plc_lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
 
 // s_waitcnt vmcnt(n) for a wave-uniform run-time n (the instruction takes an immediate): waits until
 // at most n of this wave's vector-memory operations are outstanding.  Values above the table wait
@@ -409,7 +442,7 @@ __device__ __forceinline__ void plc_conv_body(const ConvArgs& a, const int block
     // exceed the activation traffic of the light convs) cross the fabric once per workgroup.
 #pragma unroll 1
     for (int tile_id = block_x; tile_id < a.n_tiles; tile_id += a.n_blocks) {
-    if (tile_id != block_x) __syncthreads();   // every wave is done reading the previous tile
+    if (tile_id != block_x) plc_lds_barrier();   // every wave is done reading the previous tile (its stores may still be in flight)
     int bid = tile_id;
     const int tx = bid % a.tiles_x;
     bid /= a.tiles_x;
@@ -849,6 +882,7 @@ __device__ __forceinline__ void plc_conv_body(const ConvArgs& a, const int block
             }
         }
 
+        PLC_STAMP(5);   // (last pass of the tile: MFMA loop done)
         if constexpr (KSPLIT == 2) {
             // exchange partial sums: wave ks finishes row ks of the pass, its partner the other row
             float4* red = (float4*)(tile + TILE_UNITS);
@@ -863,7 +897,7 @@ __device__ __forceinline__ void plc_conv_body(const ConvArgs& a, const int block
                 for (int g = 0; g < 4; ++g)
                     mine[g * 64] = make_float4(acc[0][4 * g], acc[0][4 * g + 1], acc[0][4 * g + 2], acc[0][4 * g + 3]);
             }
-            __syncthreads();
+            plc_lds_barrier();
             if (ks == 0) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
@@ -880,7 +914,7 @@ __device__ __forceinline__ void plc_conv_body(const ConvArgs& a, const int block
                 }
                 plc_epilogue<EPI>(a, acc[NREP - 1], n, mt, n_mt, y0 + row0 + 1, x0 + px, half, cpre[NREP - 1]);
             }
-            __syncthreads();   // the exchange buffer is reused by the next pass
+            plc_lds_barrier();   // the exchange buffer is reused by the next pass (the stores above need not have retired)
         } else {
 #pragma unroll
             for (int r = 0; r < NREP; ++r) {
