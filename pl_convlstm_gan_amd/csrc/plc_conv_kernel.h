@@ -175,6 +175,35 @@ __device__ __forceinline__ void plc_epilogue(const ConvArgs& a, const f32x16_t& 
             else row(std::false_type{});
             return;
         }
+        // Likewise the data-gradient convs that apply a ReLU mask (or a product) to a plain output:
+        // the row's multiplier units are requested together, then combined and stored.
+        if (!op1 && mp && a.act == ACT_NONE) {
+            const long long o = pix * 16 + half * 8;
+            const int n_cb = a.ncb_out - 4 * mt;
+            if (n_cb <= 0) return;
+            uint2 mraw[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g)       // blocks past n_cb re-read block 0 (a valid address), unused
+                mraw[g] = *(const uint2*)(mp + o + (long long)(4 * mt + (g < n_cb ? g : 0)) * plane_b);
+            auto row = [&](auto mask_c) {
+                constexpr bool MASK = decltype(mask_c)::value;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float4 mv = unpack_bf4(mraw[g]);
+                    float v[4] = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+                    if (MASK) {
+                        v[0] = mv.x > 0.0f ? v[0] : 0.0f; v[1] = mv.y > 0.0f ? v[1] : 0.0f;
+                        v[2] = mv.z > 0.0f ? v[2] : 0.0f; v[3] = mv.w > 0.0f ? v[3] : 0.0f;
+                    } else {
+                        v[0] *= mv.x; v[1] *= mv.y; v[2] *= mv.z; v[3] *= mv.w;
+                    }
+                    if (g < n_cb) *(uint2*)(op + o + (long long)(4 * mt + g) * plane_b) = pack_bf4(v[0], v[1], v[2], v[3]);
+                }
+            };
+            if (a.mul_mode == MUL_RELU_MASK) row(std::true_type{});
+            else row(std::false_type{});
+            return;
+        }
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int cb = 4 * mt + g;
@@ -213,6 +242,17 @@ __device__ __forceinline__ void plc_epilogue(const ConvArgs& a, const f32x16_t& 
         }
     } else {  // EPI_F32_NCHW: channel = 32*mt + 8g + 4*half + j
         float* op = (float*)plc_img(a.out0, n, a.n_in);
+        if (a.cout == 1) {
+            // single-channel output (the generator's last conv): channel 0 is register 0 of the
+            // half-0 lanes of M tile 0; one store instead of 16 channel tests per lane
+            if (mt == 0 && half == 0) {
+                float t = acc[0];
+                if (a.act == ACT_RELU) t = fmaxf(t, 0.0f);
+                else if (a.act == ACT_SIGMOID) t = fast_sigmoid(t);
+                op[pix] = t;
+            }
+            return;
+        }
 #pragma unroll
         for (int g = 0; g < 4; ++g)
 #pragma unroll
