@@ -666,14 +666,18 @@ __device__ __forceinline__ void plc_conv_body(const ConvArgs& a, const int block
                 const int row0 = rg_u * RPW + pass * NREP;     // rows accumulated in this call
                 const int prow0 = row0 - NREP;                  // rows finished in this call
                 float ti = 0.f, tig = 0.f, to = 0.f, he = 0.f, cn[4] = {0.f, 0.f, 0.f, 0.f}, ge[4] = {0.f, 0.f, 0.f, 0.f};
-                unsigned hp[2] = {0u, 0u};
-                auto rec = [&](auto rc, auto gc, auto jc, float v) {   // gate values leave as bf16 pairs
+                unsigned hp[2] = {0u, 0u}, gpk[4] = {0u, 0u, 0u, 0u};
+                // gate values leave as one 8-byte store per gate and lane (4 channels of bf16): a wave's
+                // store covers 1 KiB of consecutive bytes (4-byte stores per channel pair were twice
+                // the instructions, each touching every other dword of the same lines)
+                auto rec = [&](auto rc, auto gc, auto jc, float v) {
                     if constexpr (SAVE) {
                         constexpr int r = decltype(rc)::value, g = decltype(gc)::value, j = decltype(jc)::value;
-                        if constexpr (j & 1)
-                            *(unsigned*)(gate_base + g * gate_stride + (long long)(y0 + prow0 + r) * W * 16 + lane_h +
-                                         (j >> 1) * 4) = pack_bf2(ge[g], v);
-                        else ge[g] = v;
+                        if constexpr (j == 0 || j == 2) ge[g] = v;
+                        else if constexpr (j == 1) gpk[g] = pack_bf2(ge[g], v);
+                        else
+                            *(uint2*)(gate_base + g * gate_stride + (long long)(y0 + prow0 + r) * W * 16 + lane_h) =
+                                make_uint2(gpk[g], pack_bf2(ge[g], v));
                     }
                 };
                 // Every activation is sigma(z) = 1/(1 + 2^(-z log2 e)) or tanh(z) = 1 - 2/(1 + 2^(2 z log2 e)):
