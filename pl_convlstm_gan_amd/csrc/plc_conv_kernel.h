@@ -83,12 +83,46 @@ struct ConvArgs {
     PlcTensor mul;       // EPI_ACT_CB8: optional CB8 bf16 tensor combined into the output (p may be null)
 };
 
+// source of out-of-image units for the LDS-DMA staging
+__device__ const uint4 plc_zero16 = {0u, 0u, 0u, 0u};
+
+// Loads through a selected pointer, pinned to the global address space (a select between a tensor
+// address and a __device__ constant otherwise degrades to a flat load, which also ties up lgkmcnt).
+#define PLC_AS1 __attribute__((address_space(1)))
+typedef unsigned int plc_u32x4 __attribute__((ext_vector_type(4)));     // uint4 is a class: its copy goes through a generic reference
+typedef float plc_f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 plc_gload16(const char* p) {
+    const plc_u32x4 v = *(const PLC_AS1 plc_u32x4*)p;
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ float4 plc_gload_f4(const char* p) {
+    const plc_f32x4 v = *(const PLC_AS1 plc_f32x4*)p;
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ float plc_gload4(const char* p) { return *(const PLC_AS1 float*)p; }
+
 // One 16-byte LDS unit (8 channels of pixel (gy, gx) of channel block cb) of the conv input.
+// The fp32-plane stagings select the ADDRESS (the tensor, or a zero constant outside the image) and
+// load unconditionally: a load inside `if (ok)` into a zero-initialised register makes the compiler
+// wait for every earlier load of the staging loop before the next one is issued.
 template <int STAGE, int NCB0>
 __device__ __forceinline__ uint4 plc_stage_unit(const ConvArgs& a, const char* s0, const char* s1, const char* gt,
                                                 int cb, int gy, int gx, int H, int W) {
     uint4 v = make_uint4(0, 0, 0, 0);
     const bool ok = (gy >= 0) & (gy < H) & (gx >= 0) & (gx < W);
+    if constexpr (STAGE == STAGE_COORD || STAGE == STAGE_F32_1CH) {
+        const char* const z = (const char*)&plc_zero16;
+        const float rv = plc_gload4(ok ? s0 + ((long long)gy * W + gx) * 4 : z);
+        if constexpr (STAGE == STAGE_COORD) {
+            const float row = plc_gload4(ok ? (const char*)(a.row_tab + gy) : z);
+            const float col = plc_gload4(ok ? (const char*)(a.col_tab + gx) : z);
+            v.x = pack_bf2(rv, row);        // all three are 0 outside the image: the unit is 0
+            v.y = pack_bf2(col, 0.0f);
+        } else {
+            v.x = pack_bf2(rv, 0.0f);
+        }
+        return v;
+    }
     if (ok) {
         const long long plane_b = (long long)H * W * 16;
         const long long pix = ((long long)gy * W + gx) * 16;
@@ -302,24 +336,6 @@ constexpr int plc_conv_lds_bytes() {
     return ((NCB * (TH + 2 * (KS / 2)) * (32 + 2 * (KS / 2)) + 63) / 64 * 64 * (STAGE == STAGE_CB8_GATED ? 2 : 1) +
             (KSPLIT == 2 ? 4 * 4 * 64 : 0) + 32) * 16;
 }
-
-// source of out-of-image units for the LDS-DMA staging
-__device__ const uint4 plc_zero16 = {0u, 0u, 0u, 0u};
-
-// Loads through a selected pointer, pinned to the global address space (a select between a tensor
-// address and a __device__ constant otherwise degrades to a flat load, which also ties up lgkmcnt).
-#define PLC_AS1 __attribute__((address_space(1)))
-typedef unsigned int plc_u32x4 __attribute__((ext_vector_type(4)));     // uint4 is a class: its copy goes through a generic reference
-typedef float plc_f32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ uint4 plc_gload16(const char* p) {
-    const plc_u32x4 v = *(const PLC_AS1 plc_u32x4*)p;
-    return make_uint4(v.x, v.y, v.z, v.w);
-}
-__device__ __forceinline__ float4 plc_gload_f4(const char* p) {
-    const plc_f32x4 v = *(const PLC_AS1 plc_f32x4*)p;
-    return make_float4(v.x, v.y, v.z, v.w);
-}
-__device__ __forceinline__ float plc_gload4(const char* p) { return *(const PLC_AS1 float*)p; }
 
 // Workgroup barrier that orders LDS accesses only.  __syncthreads() carries a workgroup-scope
 // fence, for which the compiler also waits vmcnt(0): after an epilogue that means waiting for the
@@ -570,9 +586,9 @@ __device__ __forceinline__ void plc_conv_body(const ConvArgs& a, const int block
                     const int r = u - cb * PLANE;
                     const int ly = r / LW;
                     const int lx = r - ly * LW;
-                    v[k] = make_uint4(0, 0, 0, 0);
-                    if (u < NCB * PLANE)
-                        v[k] = plc_stage_unit<STAGE, NCB0>(a, s0, s1, gt, cb, y0 - PAD + ly, x0 - PAD + lx, H, W);
+                    // (units past the tile get row -1, i.e. the zero unit, so the loads stay unconditional)
+                    v[k] = plc_stage_unit<STAGE, NCB0>(a, s0, s1, gt, cb, u < NCB * PLANE ? y0 - PAD + ly : -1,
+                                                       x0 - PAD + lx, H, W);
                 }
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
