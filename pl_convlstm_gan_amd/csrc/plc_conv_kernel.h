@@ -402,6 +402,66 @@ constexpr bool plc_conv_multi_tile() {
     return EPI != EPI_LSTM && EPI != EPI_LSTM_SAVE && (STAGE == STAGE_CB8 || STAGE == STAGE_CB8_GATED);
 }
 
+// LDS-DMA requests of one input halo tile (DMA stagings): each wave instruction moves 64 consecutive
+// units (1 KiB) straight from global memory into the tile, no VGPRs and no ds_write; out-of-image
+// units read a 16-byte block of zeros instead.  All of a wave's pieces are in flight together (the
+// caller waits).  Gated staging: the multiplier's tile is fetched the same way into a second region
+// GATE_OFF units after the tile.  SPLIT: the pieces holding rows that pass 0 of each of the RG row
+// groups reads are requested first; the return value is the number of later pieces this wave issued
+// (loads retire in order, so "all but the n_late youngest" is exactly the early set).
+template <int NCB0, int NCB1, int KS, int TH, int STAGE, bool SPLIT, int RG, int RPW, int NREP, int TILE_UNITS, int GATE_OFF>
+__device__ __forceinline__ int plc_dma_issue(const ConvArgs& a, uint4* tile, int lane, int wave_u, int n, int x0, int y0) {
+    constexpr int NCB = NCB0 + NCB1, PAD = KS / 2, LH = TH + 2 * PAD, LW = 32 + 2 * PAD, PLANE = LH * LW;
+    constexpr int NCHUNK = TILE_UNITS / 64;
+    const int H = a.H, W = a.W;
+    const char* s0 = plc_img(a.src0, n, a.n_in);
+    const char* s1 = NCB1 > 0 ? plc_img(a.src1, n, a.n_in) : nullptr;
+    const char* gt = STAGE == STAGE_CB8_GATED ? plc_img(a.gate, n, a.n_in) : nullptr;
+    const long long plane_b = (long long)H * W * 16;
+    int n_late = 0;
+    for (int phase = 0; phase < (SPLIT ? 2 : 1); ++phase)
+        for (int ch = wave_u; ch < NCHUNK; ch += 4) {
+            if constexpr (SPLIT) {
+                // wave-uniform: does piece ch hold a unit that pass 0 reads?
+                const int r0 = (ch * 64) % PLANE;
+                bool early = r0 + 63 >= PLANE;                      // runs into the next plane's first rows
+                const int lya = r0 / LW, lyb = (r0 + 63) / LW;
+#pragma unroll
+                for (int g = 0; g < RG; ++g) early |= (lya <= g * RPW + NREP + KS - 2) & (lyb >= g * RPW);
+                if (early != (phase == 0)) continue;
+                n_late += phase;
+            }
+            const int u = ch * 64 + lane;
+            const int cb = u / PLANE;
+            const int r = u - cb * PLANE;
+            const int ly = r / LW;
+            const int lx = r - ly * LW;
+            const int gy = y0 - PAD + ly, gx = x0 - PAD + lx;
+            const bool ok = (cb < NCB) & (gy >= 0) & (gy < H) & (gx >= 0) & (gx < W) & !(a.zero_state && cb >= NCB0);
+            const char* base = (cb < NCB0) ? (s0 + cb * plane_b) : (s1 + (cb - NCB0) * plane_b);
+            const long long poff = cb * plane_b + ((long long)gy * W + gx) * 16;
+            const char* src = ok ? base + ((long long)gy * W + gx) * 16 : (const char*)&plc_zero16;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(tile + ch * 64), 16, 0, 0);
+            if constexpr (STAGE == STAGE_CB8_GATED) {
+                const char* gsrc = ok ? gt + poff : (const char*)&plc_zero16;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                                 (__attribute__((address_space(3))) void*)(tile + GATE_OFF + ch * 64), 16, 0, 0);
+            }
+        }
+    return n_late;
+}
+
+// Tile index (image-major, then tile row, then tile column) -> image and pixel origin.
+__device__ __forceinline__ void plc_decode_tile(const ConvArgs& a, int th, int id, int& n, int& x0, int& y0) {
+    const int tx = id % a.tiles_x;
+    id /= a.tiles_x;
+    const int ty = id % a.tiles_y;
+    n = id / a.tiles_y;
+    x0 = tx * 32;
+    y0 = ty * th;
+}
+
 // The work of one workgroup: tile `block_x` (image-major, then tile row, then tile column) of M
 // group `block_y` of `n_mgroups`; `tile` is the workgroup's dynamic LDS.
 template <int NCB0, int NCB1, int NMT, int KS, int STAGE, int EPI, int TH, int KSPLIT = 1>
@@ -496,15 +556,40 @@ __device__ __forceinline__ void plc_conv_body(const ConvArgs& a, const int block
     // A launch holds at most as many workgroups as the chip keeps resident; with more tiles than
     // that each workgroup walks several, so the weights (whose re-fetch from L2 would otherwise
     // exceed the activation traffic of the light convs) cross the fabric once per workgroup.
+    constexpr int NCHUNK = TILE_UNITS / 64;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    // (free functions and a macro rather than capturing lambdas: this compiler's simplifycfg crashes
+    // on lambdas of this shape in the multi-tile instantiations)
+#define PLC_DMA_ISSUE(n_, x0_, y0_)                                                                     \
+    plc_dma_issue<NCB0, NCB1, KS, TH, STAGE, SPLIT_STAGE, RG, RPW, NREP, TILE_UNITS,                    \
+                  TILE_UNITS + RED_UNITS + BIAS_UNITS>(a, tile, lane, wave_u, n_, x0_, y0_)
+    // Multi-tile workgroups request tile k+1 as soon as every wave has finished READING tile k (after
+    // the last pass's MFMA loop), so the transfer runs under that pass's stores: the epilogue does
+    // not touch the LDS tile.  (Timeline of the gated post conv before: 3.4 us tile wait, 0.9 us
+    // MFMAs, 1.4 us stores per tile.)  The first tile is requested here.
+    constexpr bool PREFETCH = plc_conv_multi_tile<STAGE, EPI>();
+    if constexpr (PREFETCH) {
+        int n_, x0_, y0_;
+        plc_decode_tile(a, TH, block_x, n_, x0_, y0_);
+        PLC_DMA_ISSUE(n_, x0_, y0_);
+    }
+    // every wave runs this once per tile (it contains a workgroup barrier)
+#define PLC_PREFETCH_NEXT()                                                                             \
+    do {                                                                                                \
+        if constexpr (PREFETCH) {                                                                       \
+            const int next_ = tile_id + a.n_blocks;                                                     \
+            if (next_ < a.n_tiles) {                                                                    \
+                plc_lds_barrier(); /* every wave is done reading the current tile */                    \
+                int pn_, px0_, py0_;                                                                    \
+                plc_decode_tile(a, TH, next_, pn_, px0_, py0_);                                         \
+                PLC_DMA_ISSUE(pn_, px0_, py0_);                                                         \
+            }                                                                                           \
+        }                                                                                               \
+    } while (0)
 #pragma unroll 1
     for (int tile_id = block_x; tile_id < a.n_tiles; tile_id += a.n_blocks) {
-    if (tile_id != block_x) plc_lds_barrier();   // every wave is done reading the previous tile (its stores may still be in flight)
-    int bid = tile_id;
-    const int tx = bid % a.tiles_x;
-    bid /= a.tiles_x;
-    const int ty = bid % a.tiles_y;
-    const int n = bid / a.tiles_y;
-    const int x0 = tx * 32, y0 = ty * TH;
+    int n, x0, y0;
+    plc_decode_tile(a, TH, tile_id, n, x0, y0);
 
     PLC_STAMP(1);
     // ---- stage the input halo tile into LDS ----------------------------------------------
@@ -513,52 +598,11 @@ __device__ __forceinline__ void plc_conv_body(const ConvArgs& a, const int block
         const char* s1 = NCB1 > 0 ? plc_img(a.src1, n, a.n_in) : nullptr;
         const char* gt = STAGE == STAGE_CB8_GATED ? plc_img(a.gate, n, a.n_in) : nullptr;
         if constexpr (STAGE == STAGE_CB8 || STAGE == STAGE_CB8_GATED) {
-            // LDS-DMA: each wave instruction moves 64 consecutive units (1 KiB) straight from
-            // global memory into the tile, no VGPRs and no ds_write; out-of-image units read a
-            // 16-byte block of zeros instead.  All of a wave's pieces are in flight together.
-            // Gated staging: the multiplier's tile is fetched the same way into a second region
-            // and the product (rounded to bf16 once) replaces the tile in a pass over LDS.
-            constexpr int NCHUNK = TILE_UNITS / 64;
-            const long long plane_b = (long long)H * W * 16;
-            const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-            // Pipelined LSTM path: the pieces holding rows that pass 0 reads are requested first and
-            // only they are awaited before it; the rest of the tile lands while pass 0 runs (the
-            // loads retire in order, so "all but the n_late youngest" is exactly the early set).
-            auto early_piece = [&](int ch) {      // wave-uniform
-                const int u0 = ch * 64, r0 = u0 % PLANE;
-                if (r0 + 63 >= PLANE) return true;                  // runs into the next plane's first rows
-                const int lya = r0 / LW, lyb = (r0 + 63) / LW;
-                bool hit = false;
-#pragma unroll
-                for (int g = 0; g < RG; ++g) hit |= (lya <= g * RPW + NREP + KS - 2) & (lyb >= g * RPW);
-                return hit;
-            };
+            // (multi-tile kernels: this tile's requests were issued before the loop / during the
+            // previous tile's last pass).  Gated staging: the product (rounded to bf16 once)
+            // replaces the tile in a pass over LDS.
             int n_late = 0;
-            for (int phase = 0; phase < (SPLIT_STAGE ? 2 : 1); ++phase)
-            for (int ch = wave_u; ch < NCHUNK; ch += 4) {
-                if (SPLIT_STAGE) {
-                    if (early_piece(ch) != (phase == 0)) continue;
-                    n_late += phase;
-                }
-                const int u = ch * 64 + lane;
-                const int cb = u / PLANE;
-                const int r = u - cb * PLANE;
-                const int ly = r / LW;
-                const int lx = r - ly * LW;
-                const int gy = y0 - PAD + ly, gx = x0 - PAD + lx;
-                const bool ok = (cb < NCB) & (gy >= 0) & (gy < H) & (gx >= 0) & (gx < W) & !(a.zero_state && cb >= NCB0);
-                const char* base = (cb < NCB0) ? (s0 + cb * plane_b) : (s1 + (cb - NCB0) * plane_b);
-                const long long poff = cb * plane_b + ((long long)gy * W + gx) * 16;
-                const char* src = ok ? base + ((long long)gy * W + gx) * 16 : (const char*)&plc_zero16;
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                                 (__attribute__((address_space(3))) void*)(tile + ch * 64), 16, 0, 0);
-                if constexpr (STAGE == STAGE_CB8_GATED) {
-                    const char* gsrc = ok ? gt + poff : (const char*)&plc_zero16;
-                    __builtin_amdgcn_global_load_lds(
-                        (const __attribute__((address_space(1))) void*)gsrc,
-                        (__attribute__((address_space(3))) void*)(tile + TILE_UNITS + RED_UNITS + BIAS_UNITS + ch * 64), 16, 0, 0);
-                }
-            }
+            if constexpr (!PREFETCH) n_late = PLC_DMA_ISSUE(n, x0, y0);
             if constexpr (SPLIT_STAGE) plc_wait_vmcnt_le(n_late);
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if constexpr (STAGE == STAGE_CB8_GATED) {
@@ -943,6 +987,10 @@ __device__ __forceinline__ void plc_conv_body(const ConvArgs& a, const int block
         }
 
         PLC_STAMP(5);   // (last pass of the tile: MFMA loop done)
+        const bool last_pass = pass == PASSES - 1;
+        if constexpr (KSPLIT == 1) {
+            if (last_pass) PLC_PREFETCH_NEXT();         // next tile's DMA runs under this pass's stores
+        }
         if constexpr (KSPLIT == 2) {
             // exchange partial sums: wave ks finishes row ks of the pass, its partner the other row
             float4* red = (float4*)(tile + TILE_UNITS);
@@ -964,6 +1012,7 @@ __device__ __forceinline__ void plc_conv_body(const ConvArgs& a, const int block
                     const float4 t = theirs[g * 64];
                     acc[0][4 * g] += t.x; acc[0][4 * g + 1] += t.y; acc[0][4 * g + 2] += t.z; acc[0][4 * g + 3] += t.w;
                 }
+                if (last_pass) PLC_PREFETCH_NEXT();      // (after the exchange's LDS reads, before the stores)
                 plc_epilogue<EPI>(a, acc[0], n, mt, n_mt, y0 + row0, x0 + px, half, cpre[0]);
             } else {
 #pragma unroll
@@ -972,6 +1021,7 @@ __device__ __forceinline__ void plc_conv_body(const ConvArgs& a, const int block
                     acc[NREP - 1][4 * g] += t.x; acc[NREP - 1][4 * g + 1] += t.y;
                     acc[NREP - 1][4 * g + 2] += t.z; acc[NREP - 1][4 * g + 3] += t.w;
                 }
+                if (last_pass) PLC_PREFETCH_NEXT();
                 plc_epilogue<EPI>(a, acc[NREP - 1], n, mt, n_mt, y0 + row0 + 1, x0 + px, half, cpre[NREP - 1]);
             }
             plc_lds_barrier();   // the exchange buffer is reused by the next pass (the stores above need not have retired)
@@ -990,6 +1040,8 @@ __device__ __forceinline__ void plc_conv_body(const ConvArgs& a, const int block
 #endif
     if constexpr (!plc_conv_multi_tile<STAGE, EPI>()) break;
     }   // tile loop
+#undef PLC_PREFETCH_NEXT
+#undef PLC_DMA_ISSUE
 }
 
 template <int NCB0, int NCB1, int NMT, int KS, int STAGE, int EPI, int TH, int KSPLIT = 1>
