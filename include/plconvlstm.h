@@ -259,6 +259,21 @@ int plc_clip_adam_step(const plc_opt_tensor* t, int n, double max_norm, double l
                        double eps, double weight_decay, long long step, float* grad_norm,
                        void* workspace, size_t workspace_bytes, void* stream);
 
+/* The same step with the reference's NaN-batch skip (src/training/trainer.py:306-308,
+ * `if torch.isnan(loss): continue`) decided on the device, so that the host can launch the backward
+ * pass and this step without waiting for the loss:
+ *   guard        device float (the loss; may be NULL = never skip).  If it is NaN the call changes
+ *                nothing: parameters, moments, gradients and the counter stay as they are.
+ *   step_counter device int64, the number of updates applied so far (0 for a fresh optimizer); it is
+ *                incremented by an applied update and its new value is the `step` of the formula
+ *                above (bias corrections formed in double on the device).
+ *   skipped      device int (may be NULL): 1 if this call was skipped, else 0.
+ * `grad_norm` is written in both cases.  Three launches, no host synchronisation.  The workspace
+ * (plc_clip_adam_workspace_bytes) must be 16-byte aligned. */
+int plc_clip_adam_step_guarded(const plc_opt_tensor* t, int n, double max_norm, double lr, double beta1, double beta2,
+                               double eps, double weight_decay, const float* guard, long long* step_counter,
+                               int* skipped, float* grad_norm, void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -20,7 +20,7 @@ EXPORTS = (
     "plc_convlstm_cell_bwd_workspace_bytes", "plc_convlstm_cell_bwd", "plc_lstm_pointwise_bwd",
     "plc_generator_bwd_workspace_bytes", "plc_generator_rollout_bwd",
     "plc_combined_loss_workspace_bytes", "plc_combined_loss",
-    "plc_clip_adam_workspace_bytes", "plc_clip_adam_step",
+    "plc_clip_adam_workspace_bytes", "plc_clip_adam_step", "plc_clip_adam_step_guarded",
 )
 
 _f = C.c_void_p   # device pointers travel as plain addresses
@@ -136,6 +136,9 @@ def lib():
     L.plc_clip_adam_step.restype = i
     L.plc_clip_adam_step.argtypes = [C.POINTER(OptTensor), i, C.c_double, C.c_double, C.c_double, C.c_double,
                                      C.c_double, C.c_double, C.c_longlong, p, p, sz, p]
+    L.plc_clip_adam_step_guarded.restype = i
+    L.plc_clip_adam_step_guarded.argtypes = [C.POINTER(OptTensor), i, C.c_double, C.c_double, C.c_double, C.c_double,
+                                             C.c_double, C.c_double, p, p, p, p, p, sz, p]
     _lib = L
     return L
 

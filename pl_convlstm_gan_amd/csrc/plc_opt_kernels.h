@@ -34,6 +34,36 @@ struct AdamScalars {
     float weight_decay;    // L2 (added to the gradient), as torch.optim.Adam
 };
 
+// Guarded step: whether this call applies its update is decided ON THE DEVICE from a guard scalar
+// (the loss: NaN means "skip this batch", src/training/trainer.py:306-308 of the reference), so the
+// host need not wait for the loss before launching the backward pass.  The update count lives in
+// device memory and only advances when an update is applied; the bias corrections are formed from
+// it here, in double like the host path.
+struct AdamDyn {
+    float step_size;   // lr / (1 - beta1^step)
+    float bc2_sqrt;    // sqrt(1 - beta2^step)
+    int apply;         // 0: leave parameters, optimizer state and gradients untouched
+    int pad;
+};
+
+__global__ void plc_adam_prepare_kernel(const float* guard, long long* step_counter, int* skipped, double lr,
+                                        double beta1, double beta2, AdamDyn* out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const float gv = guard ? *guard : 0.0f;
+    const bool skip = gv != gv;
+    long long s = *step_counter;
+    if (!skip) {
+        s += 1;
+        *step_counter = s;
+    }
+    if (skipped) *skipped = skip ? 1 : 0;
+    const double sd = (double)(s < 1 ? 1 : s);
+    out->step_size = (float)(lr / (1.0 - pow(beta1, sd)));
+    out->bc2_sqrt = (float)sqrt(1.0 - pow(beta2, sd));
+    out->apply = skip ? 0 : 1;
+    out->pad = 0;
+}
+
 __device__ __forceinline__ int plc_opt_find(const OptTable& tb, long long e) {
     int k = 0;
     while (k + 1 < tb.n && e >= tb.start[k + 1]) ++k;
@@ -69,13 +99,18 @@ __global__ __launch_bounds__(256) void plc_grad_sqnorm_kernel(const OptTable tb,
 }
 
 __global__ __launch_bounds__(256) void plc_clip_adam_kernel(const OptTable tb, const float* partials, int n_partials,
-                                                            const AdamScalars sc, float* grad_norm) {
+                                                            AdamScalars sc, float* grad_norm, const AdamDyn* dyn) {
     __shared__ float red[4];
     float s = 0.0f;
     for (int i = threadIdx.x; i < n_partials; i += 256) s += partials[i];
     const float norm = sqrtf(plc_opt_block_sum(s, red));
     const float clip = sc.max_norm > 0.0f ? fminf(sc.max_norm / (norm + 1e-6f), 1.0f) : 1.0f;
     if (grad_norm && blockIdx.x == 0 && threadIdx.x == 0) *grad_norm = norm;
+    if (dyn) {                          // guarded step: scalars and the apply/skip decision come from the device
+        if (!dyn->apply) return;        // (uniform over the launch)
+        sc.step_size = dyn->step_size;
+        sc.bc2_sqrt = dyn->bc2_sqrt;
+    }
     const long long total = tb.start[tb.n];
     const long long base = (long long)blockIdx.x * OPT_ELEMS_PER_BLOCK;
 #pragma unroll

@@ -160,7 +160,8 @@ class Trainer:
                 continue
             loss, parts, fake_hr, skipped = train_step(
                 self.model, self.loss_module, self.optimizer, lr, dem, lu, s_coords, s_values,
-                max_norm=self.config.training.grad_clip_norm, forward_kwargs=self._forward_kwargs())
+                max_norm=self.config.training.grad_clip_norm, forward_kwargs=self._forward_kwargs(),
+                nan_check="device")     # the skip is decided by the optimizer kernel; `skipped` is read below, after the step is queued
             if self.optimize_lazy_blocks and self.model.upsample_blocks is not None and len(self.optimizer.param_groups) == 1 \
                     and len(self.model.upsample_blocks) > 0:
                 self.optimizer.add_param_group({"params": list(self.model.upsample_blocks.parameters())})

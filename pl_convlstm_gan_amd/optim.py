@@ -28,6 +28,28 @@ class FusedAdam(torch.optim.Optimizer):
                         foreach=None, capturable=False, differentiable=False, fused=None,
                         decoupled_weight_decay=False)
         super().__init__(params, defaults)
+        # guarded steps (clip_and_step(..., guard=loss)): the update count lives on the device
+        self._dev_step: Optional[torch.Tensor] = None     # int64[1], applied updates of the tracked parameters
+        self._dev_params = []                             # the parameters that counter speaks for
+        self._unsynced = False                            # their host-side `step` entries may be ahead of it
+        self.last_skipped: Optional[torch.Tensor] = None  # int32[1] on the GPU: outcome of the last guarded step
+
+    def sync_steps(self):
+        """Bring the host-side ``step`` entries in line with the device counter of the guarded
+        steps (one host synchronisation; a no-op when nothing is pending)."""
+        if self._unsynced and self._dev_step is not None:
+            v = float(self._dev_step.item())
+            for p in self._dev_params:
+                self.state[p]["step"].fill_(v)
+        self._unsynced = False
+
+    def state_dict(self):
+        self.sync_steps()
+        return super().state_dict()
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        self._dev_step, self._dev_params, self._unsynced = None, [], False
 
     def _state_of(self, p):
         st = self.state[p]
@@ -43,8 +65,11 @@ class FusedAdam(torch.optim.Optimizer):
         if not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous():
             raise RuntimeError(f"FusedAdam: {what} must be a contiguous fp32 GPU tensor (there is no CPU path)")
 
-    def _launch(self, entries, max_norm, hp, step, device):
-        """entries: list of (param, update flag).  Returns the pre-clip norm (1-element tensor)."""
+    def _launch(self, entries, max_norm, hp, step, device, guard=None):
+        """entries: list of (param, update flag).  Returns the pre-clip norm (1-element tensor).
+        With ``guard`` (a 1-element fp32 GPU tensor) the step is the guarded one: ``step`` is ignored,
+        the device counter ``self._dev_step`` is used, and ``self.last_skipped`` (int32[1], GPU)
+        tells afterwards whether the update was skipped."""
         L = _lib.lib()
         n = len(entries)
         table = (_lib.OptTensor * n)()
@@ -59,18 +84,43 @@ class FusedAdam(torch.optim.Optimizer):
         nbytes = L.plc_clip_adam_workspace_bytes(table, n)
         ws = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=device)
         norm = torch.empty(1, dtype=torch.float32, device=device)
-        rc = L.plc_clip_adam_step(table, n, float(max_norm), float(hp["lr"]), float(hp["betas"][0]),
-                                  float(hp["betas"][1]), float(hp["eps"]), float(hp["weight_decay"]), int(step),
-                                  norm.data_ptr(), ws.data_ptr(), nbytes, torch.cuda.current_stream(device).cuda_stream)
-        _lib.check(rc, "plc_clip_adam_step")
+        stream = torch.cuda.current_stream(device).cuda_stream
+        if guard is None:
+            rc = L.plc_clip_adam_step(table, n, float(max_norm), float(hp["lr"]), float(hp["betas"][0]),
+                                      float(hp["betas"][1]), float(hp["eps"]), float(hp["weight_decay"]), int(step),
+                                      norm.data_ptr(), ws.data_ptr(), nbytes, stream)
+            _lib.check(rc, "plc_clip_adam_step")
+        else:
+            self.last_skipped = torch.empty(1, dtype=torch.int32, device=device)
+            rc = L.plc_clip_adam_step_guarded(table, n, float(max_norm), float(hp["lr"]), float(hp["betas"][0]),
+                                              float(hp["betas"][1]), float(hp["eps"]), float(hp["weight_decay"]),
+                                              guard.data_ptr(), self._dev_step.data_ptr(), self.last_skipped.data_ptr(),
+                                              norm.data_ptr(), ws.data_ptr(), nbytes, stream)
+            _lib.check(rc, "plc_clip_adam_step_guarded")
         return norm
 
     @torch.no_grad()
-    def clip_and_step(self, clip_params: Optional[Iterable[torch.nn.Parameter]] = None, max_norm: float = 0.0):
+    def clip_and_step(self, clip_params: Optional[Iterable[torch.nn.Parameter]] = None, max_norm: float = 0.0,
+                      guard: Optional[torch.Tensor] = None):
         """clip_grad_norm_(clip_params, max_norm) then Adam on this optimizer's parameters.
         ``clip_params`` may hold parameters the optimizer does not own (they are clipped, not
         stepped).  Returns the gradient norm before clipping as a 1-element GPU tensor, or None
-        when nothing was clipped."""
+        when nothing was clipped.
+
+        ``guard`` (a scalar GPU tensor, normally the loss): the reference's ``if torch.isnan(loss):
+        continue`` decided on the device.  If it is NaN nothing changes (parameters, moments, step
+        count); otherwise the step is the ordinary one.  No host synchronisation takes place;
+        ``self.last_skipped`` (int32[1] on the GPU) holds the outcome, and the host-side ``step``
+        entries are reconciled by ``sync_steps()`` / ``state_dict()``."""
+        if guard is not None:
+            done = self._guarded(clip_params, max_norm, guard)
+            if done is not NotImplemented:
+                return done
+            self.last_skipped = None
+            if bool(torch.isnan(guard.detach()).any()):      # layouts the guarded launch does not cover: host check
+                return None
+        self.sync_steps()
+        self._dev_step = None            # the host counters lead from here on; a guarded call re-seeds the device one
         clip = [p for p in (clip_params if clip_params is not None else []) if p.grad is not None] if max_norm > 0 else []
         clip_ids = {id(p) for p in clip}
         batches = []            # (group, step, [params with grad])
@@ -102,6 +152,40 @@ class FusedAdam(torch.optim.Optimizer):
         for group, s, ps in batches:
             self._launch([(p, True) for p in ps], 0.0, group, s, device)
         return norm
+
+    def _guarded(self, clip_params, max_norm, guard):
+        """The guarded single-launch case: one parameter group, every parameter with a gradient at
+        the same step count, stepped parameters inside the clip set.  NotImplemented otherwise."""
+        if len(self.param_groups) != 1:
+            return NotImplemented
+        group = self.param_groups[0]
+        if group.get("amsgrad") or group.get("maximize"):
+            raise NotImplementedError("FusedAdam: amsgrad / maximize are not implemented")
+        ps = [p for p in group["params"] if p.grad is not None]
+        if not ps or not guard.is_cuda:
+            return NotImplemented
+        clip = [p for p in (clip_params if clip_params is not None else []) if p.grad is not None] if max_norm > 0 else []
+        stepped_ids = {id(p) for p in ps}
+        if clip and not stepped_ids <= {id(p) for p in clip}:
+            return NotImplemented
+        states = [self._state_of(p) for p in ps]
+        if self._dev_step is not None and [id(p) for p in ps] != [id(p) for p in self._dev_params]:
+            self.sync_steps()            # the set of stepped parameters changed: start over from the host counters
+            self._dev_step = None
+        if self._dev_step is None:
+            steps = {float(st["step"]) for st in states}
+            if len(steps) != 1:
+                return NotImplemented
+            self._dev_step = torch.tensor([int(steps.pop())], dtype=torch.int64, device=ps[0].device)
+            self._dev_params = ps
+        for st in states:
+            st["step"] += 1              # optimistic; sync_steps() replaces it by the device count
+        self._unsynced = True
+        g = guard.detach().reshape(-1)[:1]
+        if g.dtype != torch.float32:
+            g = g.float()
+        entries = [(p, True) for p in ps] + [(p, False) for p in clip if id(p) not in stepped_ids]
+        return self._launch(entries, max_norm if clip else 0.0, group, 0, ps[0].device, guard=g.contiguous())
 
     @torch.no_grad()
     def step(self, closure=None):

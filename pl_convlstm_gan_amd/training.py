@@ -79,18 +79,38 @@ def clip_flat_(flat: torch.Tensor, max_norm: float) -> torch.Tensor:
 
 
 def train_step(model, loss_module, optimizer, rain_lr, dem, lu, s_coords, s_values, *, max_norm: float = 0.5,
-               forward_kwargs: Optional[dict] = None, group=None, clip_params: Optional[Iterable] = None):
+               forward_kwargs: Optional[dict] = None, group=None, clip_params: Optional[Iterable] = None,
+               nan_check: str = "sync"):
     """Returns (loss, loss_dict, fake_hr, skipped).  ``clip_params`` defaults to all model
-    parameters (the reference clips over model.parameters(), lazily created blocks included)."""
+    parameters (the reference clips over model.parameters(), lazily created blocks included).
+
+    ``nan_check`` -- how the reference's ``if torch.isnan(loss): continue`` (trainer.py:306-308) is
+    carried out:
+      "sync"   the host reads the flag before launching the backward pass (``skipped`` is a bool);
+      "device" (needs optim.FusedAdam) the backward pass and the optimizer step are launched at once
+               and the optimizer's guarded step leaves parameters and state untouched when the loss
+               (of any rank) is NaN; ``skipped`` is then a 0-dim bool GPU tensor, valid once the step
+               has run -- no host synchronisation inside the step.
+    """
+    if nan_check not in ("sync", "device"):
+        raise ValueError(f"nan_check must be 'sync' or 'device', not {nan_check!r}")
+    fused = hasattr(optimizer, "clip_and_step")     # optim.FusedAdam: clip + Adam in two launches
+    on_device = nan_check == "device" and fused and rain_lr.is_cuda
     optimizer.zero_grad()
     fake_hr = model(rain_lr, dem, lu, **(forward_kwargs or {}))
     scale_factor = fake_hr.shape[-2] / rain_lr.shape[-2]
     loss, loss_dict = loss_module(fake_hr, rain_lr, s_coords, s_values, scale_factor)
-    if any_rank_true(torch.isnan(loss.detach()), group):
+    guard = None
+    if on_device:
+        guard = loss.detach().reshape(1)
+        if _world(group) > 1:                        # a NaN on any rank poisons every rank's guard
+            flag = torch.isnan(guard).to(torch.float32)
+            _all_reduce(flag, dist.ReduceOp.MAX, group)
+            guard = torch.where(flag > 0, torch.full_like(guard, float("nan")), guard)
+    elif any_rank_true(torch.isnan(loss.detach()), group):
         return loss, loss_dict, fake_hr, True
     loss.backward()
     params = list(clip_params if clip_params is not None else model.parameters())
-    fused = hasattr(optimizer, "clip_and_step")     # optim.FusedAdam: clip + Adam in two launches
     if _world(group) > 1 or not fused:
         bucket = GradBucket(params)
         flat = bucket.gather()
@@ -99,7 +119,11 @@ def train_step(model, loss_module, optimizer, rain_lr, dem, lu, s_coords, s_valu
             clip_flat_(flat, max_norm)
         bucket.scatter()
     if fused:
-        optimizer.clip_and_step(params, max_norm)
+        optimizer.clip_and_step(params, max_norm, guard=guard)
     else:
         optimizer.step()
+    if on_device:
+        skipped = optimizer.last_skipped.reshape(()).to(torch.bool) if optimizer.last_skipped is not None \
+            else torch.isnan(guard).reshape(())
+        return loss, loss_dict, fake_hr, skipped
     return loss, loss_dict, fake_hr, False

@@ -100,3 +100,103 @@ def test_second_param_group_and_many_tensors(gpu):
         opt_m.clip_and_step(mine, 0.5)
     for k, (p, q) in enumerate(zip(mine, ref)):
         assert (p - q).abs().max().item() <= 2e-6 * q.abs().max().item(), k
+
+
+def test_guarded_step_skips_nan_batches_on_the_device(gpu):
+    """clip_and_step(..., guard=loss): the reference's `if torch.isnan(loss): continue`
+    (src/training/trainer.py:306-308) decided by the optimizer kernel.  A sequence with NaN guards at
+    steps 1 and 4 must end where torch's clip + Adam ends when those batches are simply left out:
+    parameters, moments and the step count (tolerances of test_fused_adam_matches_torch)."""
+    from pl_convlstm_gan_amd.optim import FusedAdam
+    mine, ref = _make(gpu, 5), _make(gpu, 5)
+    opt_m = FusedAdam(mine[:-1], lr=5e-4)
+    opt_r = torch.optim.Adam(ref[:-1], lr=5e-4)
+    nan_steps = {1, 4}
+    for step in range(7):
+        gs = _grads(step, 1.0)
+        bad = step in nan_steps
+        for p, g in zip(mine, gs):
+            p.grad = (g * float("nan") if bad else g.clone()).to(gpu)      # a NaN loss comes with NaN gradients
+        before = [p.detach().clone() for p in mine]
+        guard = torch.tensor(float("nan") if bad else 1.25, device=gpu)
+        opt_m.clip_and_step(mine, 0.5, guard=guard)
+        assert int(opt_m.last_skipped.item()) == int(bad)
+        if bad:
+            for p, b in zip(mine, before):
+                assert torch.equal(p.detach(), b)
+            continue
+        for q, g in zip(ref, gs):
+            q.grad = g.clone().to(gpu)
+        torch.nn.utils.clip_grad_norm_(ref, 0.5)
+        opt_r.step()
+    for k, (p, q) in enumerate(zip(mine, ref)):
+        assert torch.isfinite(p).all()
+        assert (p - q).abs().max().item() <= 2e-6 * q.abs().max().item(), k
+    sd = opt_m.state_dict()                                   # reconciles the host-side step entries
+    for p, q in zip(mine[:-1], ref[:-1]):
+        sm, sr = opt_m.state[p], opt_r.state[q]
+        assert float(sm["step"]) == float(sr["step"]) == 5.0
+        assert (sm["exp_avg"] - sr["exp_avg"]).abs().max().item() <= 2e-6 * sr["exp_avg"].abs().max().item()
+        assert (sm["exp_avg_sq"] - sr["exp_avg_sq"]).abs().max().item() <= 2e-6 * sr["exp_avg_sq"].abs().max().item()
+    assert all(float(s["step"]) == 5.0 for s in sd["state"].values())
+
+
+def test_guarded_and_plain_steps_interleave(gpu):
+    """A plain step after guarded ones starts from the reconciled count, and a guarded step after a
+    plain one re-seeds the device counter: the mixture equals six plain torch steps."""
+    from pl_convlstm_gan_amd.optim import FusedAdam
+    mine, ref = _make(gpu, 6), _make(gpu, 6)
+    opt_m = FusedAdam(mine, lr=1e-3)
+    opt_r = torch.optim.Adam(ref, lr=1e-3)
+    ok = torch.tensor(0.5, device=gpu)
+    for step in range(6):
+        gs = _grads(step, 1.0)
+        for p, q, g in zip(mine, ref, gs):
+            p.grad = g.clone().to(gpu)
+            q.grad = g.clone().to(gpu)
+        torch.nn.utils.clip_grad_norm_(ref, 0.5)
+        opt_r.step()
+        opt_m.clip_and_step(mine, 0.5, guard=ok if step in (0, 1, 4, 5) else None)
+    for k, (p, q) in enumerate(zip(mine, ref)):
+        assert (p - q).abs().max().item() <= 2e-6 * q.abs().max().item(), k
+    opt_m.sync_steps()
+    assert all(float(opt_m.state[p]["step"]) == 6.0 for p in mine)
+
+
+def test_train_step_device_nan_check_equals_sync(gpu):
+    """training.train_step with nan_check='device' (no host sync inside the step) against the
+    default 'sync' mode: bit-identical parameters after three steps, one of them on a batch whose
+    gauge values make the loss NaN-free, and a skipped flag that is a GPU tensor."""
+    from pl_convlstm_gan_amd import Generator
+    from pl_convlstm_gan_amd.losses import CombinedLoss
+    from pl_convlstm_gan_amd.optim import FusedAdam
+    from pl_convlstm_gan_amd.training import train_step
+
+    def run(mode):
+        torch.manual_seed(11)
+        m = Generator(hidden_dims=[16, 32], lu_channels=5, scale_factor=1).to(gpu)
+        opt = FusedAdam(m.parameters(), lr=5e-4)
+        g = torch.Generator().manual_seed(12)
+        flags = []
+        for step in range(3):
+            rain = (10 * torch.rand(2, 3, 1, 16, 32, generator=g)).to(gpu)
+            if step == 1:
+                rain[0, 0, 0, 0, 0] = float("nan")            # poisons the output, hence the loss
+            dem = torch.rand(2, 1, 16, 32, generator=g).to(gpu)
+            lu = torch.rand(2, 5, 16, 32, generator=g).to(gpu)
+            coords = torch.randint(0, 16, (6, 2), generator=g).to(gpu)
+            values = (20 * torch.rand(2, 3, 6, generator=g)).to(gpu)
+            _, _, _, skipped = train_step(m, CombinedLoss(), opt, rain, dem, lu, coords, values, nan_check=mode)
+            flags.append(skipped)
+        torch.cuda.synchronize()
+        return [p.detach().clone() for p in m.parameters()], flags, opt
+
+    p_sync, f_sync, _ = run("sync")
+    p_dev, f_dev, opt = run("device")
+    assert f_sync == [False, True, False]
+    assert all(isinstance(f, torch.Tensor) and f.is_cuda for f in f_dev)
+    assert [bool(f) for f in f_dev] == [False, True, False]
+    for a, b in zip(p_sync, p_dev):
+        assert torch.isfinite(b).all() and torch.equal(a, b)
+    opt.sync_steps()
+    assert {float(s["step"]) for s in opt.state.values()} == {2.0}
