@@ -120,10 +120,11 @@ static Cb8View view(const void* p, long long img) {
 
 static int lstm_pointwise_bwd(Cb8View dh0, Cb8View dh1, Cb8View dh2, const void* dc_in, const void* gates,
                               const void* c_prev, const void* c_cur, void* dz, void* dc_out, int B, int Ch, int H,
-                              int W, hipStream_t st) {
+                              int W, hipStream_t st, Cb8View dh0_mul = Cb8View{nullptr, 0}) {
     LstmBwdArgs a;
     a.B = B; a.ncb = Ch / 8; a.H = H; a.W = W;
     a.dh0 = dh0; a.dh1 = dh1; a.dh2 = dh2;
+    a.dh0_mul = dh0_mul;
     a.dc_in = (const char*)dc_in; a.gates = (const char*)gates;
     a.c_prev = (const char*)c_prev; a.c_cur = (const char*)c_cur;
     a.dz = (char*)dz; a.dc_out = (char*)dc_out;
@@ -437,6 +438,11 @@ extern "C" int plc_generator_rollout_bwd(const plc_rollout_desc* d, const plc_ro
         a.ncb_out = C2 / 8;
         if ((rc = launch_conv<4, 0, 1, 3, STAGE_CB8, EPI_ACT_CB8>(a, NI, 1, st))) return rc;
     }
+    // With no upsample block and no resize between the gates and the recurrence (scale 1), the gradient
+    // of the gated feature map IS cell 2's incoming dh: its pointwise backward then forms
+    // d_feat * gate itself (the gate is one image per batch element, cache-resident) and the
+    // T*B-image product is neither written by the gate backward nor read back.
+    const bool direct = d->n_blocks == 0 && bp.d_mid == (size_t)-1 && bp.d_up == (size_t)-1;
     // ---- gating and the two attention branches ------------------------------------------------
     {
         GateBwdArgs ga;
@@ -446,7 +452,7 @@ extern "C" int plc_generator_rollout_bwd(const plc_rollout_desc* d, const plc_ro
         ga.gate = wf + fp.gate;
         ga.gate_dem = wf + fp.gate_dem;
         ga.gate_lu = wf + fp.gate_lu;
-        ga.d_pre = wb + bp.d_pre;
+        ga.d_pre = direct ? nullptr : wb + bp.d_pre;
         ga.d_lu_pre = wb + bp.d_lu_pre;
         ga.d_dem_pre = wb + bp.d_dem_pre;
         hipLaunchKernelGGL(plc_gate_bwd_kernel, dim3(ew_grid((long long)B * (C2 / 8) * ohw)), dim3(256), 0, st, ga);
@@ -491,7 +497,7 @@ extern "C" int plc_generator_rollout_bwd(const plc_rollout_desc* d, const plc_ro
         }
     }
     // ---- PixelShuffle upsample blocks, last to first ------------------------------------------
-    const char* cur = wb + bp.d_pre;     // gradient of the feature map entering the gates
+    const char* cur = direct ? wb + bp.d_feat : wb + bp.d_pre;     // gradient of the feature map entering the gates
     // ---- bilinear feature resizes (generator.py:179-195), last to first -------------------------
     if (bp.d_mid != (size_t)-1) {
         const long long planes = (long long)NI * (C2 / 8);
@@ -546,7 +552,8 @@ extern "C" int plc_generator_rollout_bwd(const plc_rollout_desc* d, const plc_ro
                                      last ? nullptr : dc2_n, wf + fp.gates2 + (size_t)t * s2 * 4,
                                      t == 0 ? nullptr : wf + fp.c2s + (size_t)t * s2 * 2,     // c_{-1} = 0 is not stored
                                      wf + fp.c2s + (size_t)(t + 1) * s2 * 2, dz2_t,
-                                     dc2_t, B, C2, H, W, st)))
+                                     dc2_t, B, C2, H, W, st,
+                                     direct ? view(wf + fp.gate, fp.img2) : view(nullptr, 0))))
             return rc;
         if ((rc = cell_dgrad(dz2_t, wb + bp.cell2T, bpk0, dcat2_t, B, C1, C2, H, W, st))) return rc;
 

@@ -46,6 +46,9 @@ struct Cb8View {
 struct LstmBwdArgs {
     int B, ncb, H, W;              // ncb = Ch / 8
     Cb8View dh0, dh1, dh2;         // bf16 CB8 views of ncb blocks
+    Cb8View dh0_mul;               // optional (p null = none): dh0 is taken as bf16(dh0 * dh0_mul), e.g. the
+                                   // gradient of the gated feature map times the gate, formed here instead of
+                                   // being written out and read back
     const char* dc_in;             // fp32 CB8 [B][ncb] or null
     const char* gates;             // bf16 CB8 [B][4*ncb]
     const char* c_prev;            // fp32 CB8 [B][ncb] or null (= zeros: the first timestep)
@@ -70,7 +73,16 @@ __global__ void plc_lstm_pointwise_bwd_kernel(const LstmBwdArgs a) {
 #pragma unroll
         for (int k = 0; k < 3; ++k)
             if (views[k].p) {
-                const F8 t = ld_bf8(views[k].p + b * views[k].img + u * 16);
+                F8 t = ld_bf8(views[k].p + b * views[k].img + u * 16);
+                if (k == 0 && a.dh0_mul.p) {
+                    const F8 m = ld_bf8(a.dh0_mul.p + b * a.dh0_mul.img + u * 16);
+#pragma unroll
+                    for (int j = 0; j < 8; j += 2) {      // rounded to bf16 like the stored product it replaces
+                        const unsigned pk = pack_bf2(t.v[j] * m.v[j], t.v[j + 1] * m.v[j + 1]);
+                        t.v[j] = __uint_as_float(pk << 16);
+                        t.v[j + 1] = __uint_as_float(pk & 0xffff0000u);
+                    }
+                }
 #pragma unroll
                 for (int j = 0; j < 8; ++j) dh.v[j] += t.v[j];
             }
@@ -126,7 +138,7 @@ struct GateBwdArgs {
     const char* gate;       // [B]    gd * gl
     const char* gate_dem;   // [B]    gd
     const char* gate_lu;    // [B]    gl
-    char* d_pre;            // [T*B]
+    char* d_pre;            // [T*B] or null (not stored)
     char* d_lu_pre;         // [B]
     char* d_dem_pre;        // [B]
 };
@@ -151,7 +163,7 @@ __global__ void plc_gate_bwd_kernel(const GateBwdArgs a) {
                 dp.v[j] = df.v[j] * g.v[j];
                 acc.v[j] += df.v[j] * fp.v[j];
             }
-            st_bf8(a.d_pre + o, dp);
+            if (a.d_pre) st_bf8(a.d_pre + o, dp);      // null: the consumer forms d_feat * gate itself
         }
         const F8 gd = ld_bf8(a.gate_dem + idx * 16), gl = ld_bf8(a.gate_lu + idx * 16);
         F8 dl, dd;

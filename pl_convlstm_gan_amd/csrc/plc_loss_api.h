@@ -21,7 +21,9 @@ static int loss_plan(const plc_loss_desc* d, LossPlan* p) {
     p->vec = (d->out_W % 4 == 0) ? 4 : 1;
     const long long work = (long long)d->B * d->T * d->out_H * (d->out_W / p->vec);
     long long nb = (work + 255) / 256;
-    p->n_main = (int)(nb < 1 ? 1 : (nb > 2048 ? 2048 : nb));
+    // one item per thread up to 8192 blocks (a 2048 cap made a quarter of the threads of the c3 shape
+    // run a second iteration, which then set the kernel's length)
+    p->n_main = (int)(nb < 1 ? 1 : (nb > 8192 ? 8192 : nb));
     const bool identity = d->H == d->out_H && d->W == d->out_W;
     const long long cells = (long long)d->B * d->T * d->H * d->W;
     nb = (cells + 255) / 256;
