@@ -90,6 +90,7 @@ static int launch_wgrad(ConvArgs in, PlcTensor dz, int mcb_valid, int n_img, Sla
     a.dz = dz;
     if (dz_mask) a.dz_mask = *dz_mask;
     a.mcb_valid = mcb_valid;
+    a.rows_valid = cout;
     a.n_tiles = n_img * a.in.tiles_x * a.in.tiles_y;
     a.slab = slab;
     constexpr int max_blocks = wgrad_max_blocks<NCB0, NCB1, MT, KS>();

@@ -30,6 +30,7 @@ struct WgradArgs {
     PlcTensor dz;      // CB8 bf16, ceil(cout/8) channel blocks
     PlcTensor dz_mask; // optional (p may be null): CB8 bf16 like dz; dz counts only where mask > 0 (ReLU backward)
     int mcb_valid;     // channel blocks present in dz
+    int rows_valid;    // output channels of the conv: slab rows that are written (and later reduced)
     int n_tiles;       // n_img * tiles_y * tiles_x
     float* slab;       // [gridDim.x][MT*32][NT*32]
 };
@@ -315,7 +316,8 @@ __global__ __launch_bounds__(512, 2) void plc_wgrad_kernel(const WgradArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-            slab[(long long)(32 * m + row) * (G::NT * 32) + nt * 32 + col] = acc[i][r];
+            // (rows past the conv's output channels are never read by the slab reduction)
+            if (32 * m + row < a.rows_valid) slab[(long long)(32 * m + row) * (G::NT * 32) + nt * 32 + col] = acc[i][r];
         }
     }
 }
