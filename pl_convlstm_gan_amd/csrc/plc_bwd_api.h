@@ -3,18 +3,7 @@
 #pragma once
 #include "plc_bwd_kernels.h"
 #include "plc_wgrad_kernel.h"
-
-// fp32 single-channel plane per image (PlcTensor addressing) -> CB8 bf16 [N][1][H][W][8], channel 0
-__global__ void plc_plane_to_cb8_kernel(PlcTensor src, int n_in, int N, long long hw, uint4* __restrict__ dst) {
-    const long long total = (long long)N * hw;
-    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
-         idx += (long long)gridDim.x * blockDim.x) {
-        const int n = idx / hw;
-        const long long pix = idx % hw;
-        const float v = ((const float*)plc_img(src, n, n_in))[pix];
-        dst[idx] = make_uint4(pack_bf2(v, 0.0f), 0, 0, 0);
-    }
-}
+#include "plc_wgrad1_kernel.h"
 
 // ---------------------------------------------------------------------------------------------
 // weight gradient launcher
@@ -106,6 +95,46 @@ static int launch_wgrad(ConvArgs in, PlcTensor dz, int mcb_valid, int n_img, Sla
     jb.cout = cout; jb.c0 = c0; jb.c1 = c1; jb.ks = KS; jb.ncb = NCB0 + NCB1;
     const long long groups = ((long long)cout * G::NT * 32 + 31) / 32;      // 32 output elements per block pass
     jb.n_blocks = (int)(groups < 1 ? 1 : (groups > 1024 ? 1024 : groups));
+    jb.first_block = ar->blocks;
+    ar->blocks += jb.n_blocks;
+    ar->tb.job[ar->tb.n++] = jb;
+    return PLC_OK;
+}
+
+// Weight gradient of a 32 -> 1 channel 3x3 conv on the vector ALUs (plc_wgrad1_kernel.h); x is the
+// conv input (bf16 CB8, 4 channel blocks), dy the fp32 gradient planes of its output.  Queues the
+// same slab reduction as the matrix kernel.
+static size_t wgrad_cout1_slab_bytes() { return align256((size_t)W1_MAX_BLOCKS * W1_COLS * sizeof(float)); }
+static int launch_wgrad_cout1(PlcTensor x, PlcTensor dy, int n_in, int H, int W, int n_img, SlabArena* ar, float* dw,
+                              float* db, hipStream_t st) {
+    const size_t need = wgrad_cout1_slab_bytes();
+    if (ar->used + need > ar->size || ar->tb.n == FINALIZE_MAX_JOBS) {
+        int rc = arena_flush(ar, st);
+        if (rc) return rc;
+    }
+    if (need > ar->size) return plc_fail(PLC_EWORKSPACE, "wgrad: slab arena %zu < %zu bytes", ar->size, need);
+    float* slab = (float*)(ar->base + ar->used);
+    ar->used += need;
+    Wgrad1Args a;
+    memset(&a, 0, sizeof(a));
+    a.x = x; a.dy = dy; a.n_in = n_in; a.H = H; a.W = W;
+    a.strips_x = cdiv(W, 64);
+    a.strips_y = cdiv(H, W1_ROWS);
+    const long long strips = (long long)n_img * a.strips_x * a.strips_y;
+    if (strips <= 0 || strips >= (1ll << 31)) return plc_fail(PLC_EINVAL, "wgrad: bad strip count %lld", strips);
+    a.n_strips = (int)strips;
+    a.slab = slab;
+    // as many workgroups as give every one the same number of strips (+-1), at most W1_MAX_BLOCKS
+    const int per = cdiv(a.n_strips, W1_MAX_BLOCKS);
+    const int grid = cdiv(a.n_strips, per);
+    hipLaunchKernelGGL(plc_wgrad_cout1_kernel, dim3(grid), dim3(256), 0, st, a);
+    PLC_HIP(hipGetLastError());
+    FinalizeJob jb;
+    memset(&jb, 0, sizeof(jb));
+    jb.slab = slab; jb.dw = dw; jb.db = db;
+    jb.n_slabs = grid; jb.rows_pad = 1; jb.cols_pad = W1_COLS;
+    jb.cout = 1; jb.c0 = 32; jb.c1 = 0; jb.ks = 3; jb.ncb = 4;
+    jb.n_blocks = W1_COLS / 32;
     jb.first_block = ar->blocks;
     ar->blocks += jb.n_blocks;
     ar->tb.job[ar->tb.n++] = jb;
@@ -284,7 +313,7 @@ extern "C" int plc_convlstm_cell_bwd(const float* x, const float* h, const float
 // ---------------------------------------------------------------------------------------------
 struct BwdPlan {
     size_t post2T, post0T, cell1T, cell2T, lu2T, dem2T, upT[8], bpk0;
-    size_t d_out8, d_pre0, d_feat, d_pre, d_lu_pre, d_dem_pre, d_lu_mid, d_dem_mid;
+    size_t d_pre0, d_feat, d_pre, d_lu_pre, d_dem_pre, d_lu_mid, d_dem_mid;
     size_t d_conv[8], d_in[8];
     size_t d_mid, d_up;     // (size_t)-1 when the corresponding bilinear resize is absent
     size_t dz1, dz2, dcat1, dcat2, dc1, dc2, slab, slab_bytes, total;
@@ -310,7 +339,6 @@ static int bwd_plan(const plc_rollout_desc* d, const RolloutPlan& fp, BwdPlan* p
     p->dem2T = take(packedT_weight_bytes(C2, C2 / 2, 0, 1, 1));
     for (int k = 0; k < d->n_blocks; ++k) p->upT[k] = take(packedT_weight_bytes(4 * C2, C2, 0, 3, 2));
     p->bpk0 = take(8 * 32 * sizeof(float));
-    p->d_out8 = take((size_t)NI * ohw * 16);
     p->d_pre0 = take((size_t)NI * 4 * ohw * 16);
     p->d_feat = take((size_t)NI * (C2 / 8) * ohw * 16);
     p->d_pre = take((size_t)NI * (C2 / 8) * ohw * 16);
@@ -331,7 +359,7 @@ static int bwd_plan(const plc_rollout_desc* d, const RolloutPlan& fp, BwdPlan* p
     p->dc2 = take((size_t)2 * B * (C2 / 8) * hw * 32);
     // slab arena: the slabs of every weight-gradient launch of the pass, so one reduction at the end serves all
     size_t sb = wgrad_slab_bytes<2, 4, 4, 3>() + wgrad_slab_bytes<2, 2, 2, 3>();            // cell 2, cell 1
-    sb += 2 * wgrad_slab_bytes<4, 0, 1, 3>();                                                // post0, post2
+    sb += wgrad_slab_bytes<4, 0, 1, 3>() + wgrad_cout1_slab_bytes();                         // post0, post2
     sb += wgrad_slab_bytes<1, 0, 1, 3>();                                                    // stem
     sb += 2 * wgrad_slab_bytes<2, 0, 1, 1>();                                                // the two 1x1 gate convs
     sb += wgrad_slab_bytes<1, 0, 1, 3>() + max_sz(wgrad_slab_bytes<1, 0, 1, 3>(), wgrad_slab_bytes<2, 0, 1, 3>());
@@ -406,15 +434,13 @@ extern "C" int plc_generator_rollout_bwd(const plc_rollout_desc* d, const plc_ro
 
     // ---- output convs -------------------------------------------------------------------------
     const PlcTensor gout = tens(g->grad_out, (long long)T * ohw * 4, ohw * 4);   // n = t*B + b -> grad_out[b][t]
-    hipLaunchKernelGGL(plc_plane_to_cb8_kernel, dim3(ew_grid((long long)NI * ohw)), dim3(256), 0, st, gout, B, NI,
-                       ohw, (uint4*)(wb + bp.d_out8));
-    PLC_HIP(hipGetLastError());
     {
-        ConvArgs in = conv_args(oH, oW, B);
-        in.src0 = tens(wf + fp.p0, 4 * ohw * 16, (long long)B * 4 * ohw * 16);
-        if ((rc = launch_wgrad<4, 0, 1, 3, STAGE_CB8>(in, tens(wb + bp.d_out8, ohw * 16, (long long)B * ohw * 16), 1, NI,
-                                                      slab, g->post2_w, g->post2_b, 1, 32, 0, st)))
+        // the one-output-channel conv: its weight gradient streams the conv input once on the vector
+        // ALUs and reads the loss gradient in fp32 as it is
+        if ((rc = launch_wgrad_cout1(tens(wf + fp.p0, 4 * ohw * 16, (long long)B * 4 * ohw * 16), gout, B, oH, oW, NI,
+                                     slab, g->post2_w, g->post2_b, st)))
             return rc;
+        ConvArgs in;
         ConvArgs a = conv_args(oH, oW, B);
         a.src0 = gout;
         a.out0 = tens(wb + bp.d_pre0, 4 * ohw * 16, (long long)B * 4 * ohw * 16);
