@@ -13,7 +13,7 @@
 
 constexpr int W1_ROWS = 8;          // rows of one strip (a strip is W1_ROWS x 64 pixels of one image)
 constexpr int W1_COLS = 320;        // slab row: 9 taps x 32 channels, the bias sum at 288, padded to 32
-constexpr int W1_MAX_BLOCKS = 1024; // four 4-wave workgroups per CU
+constexpr int W1_MAX_BLOCKS = 768;  // three 4-wave workgroups per CU: what 150 registers per lane keep resident
 
 struct Wgrad1Args {
     PlcTensor x;    // conv input, bf16 CB8 with 4 channel blocks per image
