@@ -222,7 +222,7 @@ __device__ __forceinline__ int plc_gauge_offset(const LossArgs& a, const int* ca
 }
 
 __global__ __launch_bounds__(LOSS_FIN_THREADS) void plc_loss_finalize_kernel(const LossArgs a) {
-    __shared__ float red[LOSS_FIN_THREADS / 64];
+    __shared__ float red6[6][LOSS_FIN_THREADS / 64];
     __shared__ float sh_k;
     __shared__ int pix[LOSS_PIX_CACHE];
     const int tid = threadIdx.x;
@@ -237,8 +237,7 @@ __global__ __launch_bounds__(LOSS_FIN_THREADS) void plc_loss_finalize_kernel(con
         for (int k = 0; k < 4; ++k) s[k] += a.partials[(long long)b * 4 + k];
     }
     for (int b = tid; b < a.n_pool_blocks; b += LOSS_FIN_THREADS) s[3] += a.partials[(long long)a.n_main_blocks * 4 + b];
-    const float Sx = plc_block_sum<LOSS_FIN_THREADS / 64>(s[0], red), Sy = plc_block_sum<LOSS_FIN_THREADS / 64>(s[1], red);
-    const float St = plc_block_sum<LOSS_FIN_THREADS / 64>(s[2], red), Sc = plc_block_sum<LOSS_FIN_THREADS / 64>(s[3], red);   // (also orders pix[] writes)
+    __syncthreads();   // pix[] is complete
 
     // rain-gauge term: one (frame, station) element per thread and iteration
     const long long plane = (long long)a.Hh * a.Wh;
@@ -255,7 +254,24 @@ __global__ __launch_bounds__(LOSS_FIN_THREADS) void plc_loss_finalize_kernel(con
         psum += fabsf(a.pred[(long long)f * plane + o] - obs) * plc_gauge_weight(obs, a.weight_mode);
         pcnt += 1.0f;
     }
-    const float Ps = plc_block_sum<LOSS_FIN_THREADS / 64>(psum, red), Pc = plc_block_sum<LOSS_FIN_THREADS / 64>(pcnt, red);
+    // the six sums in one pass over the block: wave sums, then the waves in a fixed order (one
+    // barrier instead of twelve; the loads of the partials and of the gauge pixels overlap)
+    float v6[6] = {s[0], s[1], s[2], s[3], psum, pcnt};
+#pragma unroll
+    for (int k = 0; k < 6; ++k) v6[k] = plc_wave_sum(v6[k]);
+    if ((tid & 63) == 0) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) red6[k][tid >> 6] = v6[k];
+    }
+    __syncthreads();
+    float tot[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        tot[k] = 0.0f;
+#pragma unroll
+        for (int w = 0; w < LOSS_FIN_THREADS / 64; ++w) tot[k] += red6[k][w];
+    }
+    const float Sx = tot[0], Sy = tot[1], St = tot[2], Sc = tot[3], Ps = tot[4], Pc = tot[5];
     if (tid == 0) {
         const float fB = (float)a.B, fT = (float)a.T, fH = (float)a.Hh, fW = (float)a.Wh;
         const float point = Pc > 0.0f ? Ps / Pc : 0.0f;

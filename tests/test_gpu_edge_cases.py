@@ -21,6 +21,7 @@ CASES = [
     (1, 2, 33, 17, 1, 16, None),     # just past a tile boundary in y, the maximum of 16 LU channels
     (2, 3, 6, 4, 2, 5, (7, 9)),      # one upsample block, aux maps at an unrelated resolution
     (1, 2, 5, 6, 4, 3, None),        # two upsample blocks
+    (2, 2, 20, 70, 1, 5, None),      # wider than one 64-column strip of the one-channel weight gradient, ragged in both axes
 ]
 
 
