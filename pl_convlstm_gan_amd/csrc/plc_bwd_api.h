@@ -75,7 +75,7 @@ static int launch_wgrad(ConvArgs in, PlcTensor dz, int mcb_valid, int n_img, Sla
     memset(&a, 0, sizeof(a));
     a.in = in;
     a.in.tiles_x = cdiv(in.W, 32);
-    a.in.tiles_y = cdiv(in.H, WG_TH);
+    a.in.tiles_y = cdiv(in.H, G::TH);
     a.dz = dz;
     if (dz_mask) a.dz_mask = *dz_mask;
     a.mcb_valid = mcb_valid;

@@ -35,7 +35,7 @@ struct WgradArgs {
     float* slab;       // [gridDim.x][MT*32][NT*32]
 };
 
-constexpr int WG_TH = 4;
+constexpr int WG_TH = 4;            // rows of a tile (WgradGeom::TH doubles it for the narrow convs)
 constexpr int WG_PF_DEPTH = 4;     // B fragments requested ahead of the MFMA that consumes them (6 measured no better)
 
 // eight bf16 1.0: the "keep everything" ReLU mask of launches without one
@@ -45,9 +45,14 @@ __device__ const uint4 plc_ones16 = {0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F
 
 template <int NCB, int MT, int KS>
 struct WgradGeom {
+    // Rows of a tile.  The narrow convs (one 32-row block of outputs, at most two input channel
+    // blocks) do few MFMAs per pixel, so their time is the per-tile cost of loads and barriers: 8 rows
+    // halve it and two workgroups still fit a CU (stem: 88 -> 66 us; 16 rows: 74 us; the 4-block
+    // gated conv with 8 rows fits one workgroup only and was slower, 132 -> 140 us).
+    static constexpr int TH = (MT == 1 && NCB <= 2) ? 2 * WG_TH : WG_TH;
     static constexpr int TAPS = KS * KS;
     static constexpr int PAD = KS / 2;
-    static constexpr int LH = WG_TH + 2 * PAD;
+    static constexpr int LH = TH + 2 * PAD;
     static constexpr int LW = 32 + 2 * PAD;
     static constexpr int PLANE = LH * LW;
     static constexpr int MCB = 4 * MT;
@@ -57,13 +62,13 @@ struct WgradGeom {
     static constexpr int WN = 8 / MT;                   // N groups of waves
     static constexpr int NT_W = (NT + WN - 1) / WN;
     static constexpr int IN_UNITS = NCB * PLANE;
-    static constexpr int DZ_UNITS = MCB * WG_TH * 32;   // dz units of a tile (what the loader fetches)
+    static constexpr int DZ_UNITS = MCB * TH * 32;   // dz units of a tile (what the loader fetches)
     // In LDS each dz channel block is padded by 4 units: the four blocks a 32-lane group reads for
     // an A fragment then start 64 B apart mod 256 and tile the bank row; at the natural stride
     // (2048 B = 0 mod 256) they collide 4-way, which made up most of the kernel's bank conflicts.
-    static constexpr int DZ_CB = WG_TH * 32 + 4;
+    static constexpr int DZ_CB = TH * 32 + 4;
     static constexpr int DZ_LDS_UNITS = MCB * DZ_CB;
-    static constexpr int CONST_UNITS = 128;             // 2 KiB: covers every k-step offset of a tile
+    static constexpr int CONST_UNITS = ((TH - 1) * LW + 21 + 15) / 16 * 16;   // covers every k-step offset of a tile
     static constexpr int CONST_BASE = IN_UNITS + DZ_LDS_UNITS;
     static constexpr int BUF_UNITS = CONST_BASE + 2 * CONST_UNITS;   // [in | dz | zeros | ones]
     static constexpr int LDS_BYTES = 2 * BUF_UNITS * 16;
@@ -75,7 +80,7 @@ __global__ __launch_bounds__(512, 2) void plc_wgrad_kernel(const WgradArgs a) {
     using G = WgradGeom<NCB0 + NCB1, MT, KS>;
     constexpr int NCB = NCB0 + NCB1;
     static_assert(MT == 1 || MT == 2 || MT == 4, "MT must be 1, 2 or 4");
-    static_assert(((WG_TH - 1) * G::LW + 16) * 16 + 80 <= G::CONST_UNITS * 16, "constant region too small");
+    static_assert(((G::TH - 1) * G::LW + 16) * 16 + 80 <= G::CONST_UNITS * 16, "constant region too small");
     extern __shared__ __attribute__((aligned(16))) uint4 smem[];
 
     const int tid = threadIdx.x;
@@ -147,7 +152,7 @@ __global__ __launch_bounds__(512, 2) void plc_wgrad_kernel(const WgradArgs a) {
         const int n = t / tiles_per_img;
         const int rem = t - n * tiles_per_img;
         const int ty = rem / a.in.tiles_x, tx = rem - ty * a.in.tiles_x;
-        const int x0 = tx * 32, y0 = ty * WG_TH;
+        const int x0 = tx * 32, y0 = ty * G::TH;
         const char* s0 = plc_img(a.in.src0, n, a.in.n_in);
         const char* s1 = NCB1 > 0 ? plc_img(a.in.src1, n, a.in.n_in) : nullptr;
         const char* gt = STAGE == STAGE_CB8_GATED ? plc_img(a.in.gate, n, a.in.n_in) : nullptr;
@@ -185,8 +190,8 @@ __global__ __launch_bounds__(512, 2) void plc_wgrad_kernel(const WgradArgs a) {
                 }
             } else if (u < G::IN_UNITS + G::DZ_UNITS) {
                 const int d = u - G::IN_UNITS;
-                const int cb = d / (WG_TH * 32);
-                const int r = d - cb * (WG_TH * 32);
+                const int cb = d / (G::TH * 32);
+                const int r = d - cb * (G::TH * 32);
                 const int gy = y0 + (r >> 5), gx = x0 + (r & 31);
                 const bool ok = (cb < a.mcb_valid) & (gy < H) & (gx < W);
                 const long long off = (((long long)cb * H + gy) * W + gx) * 16;
@@ -237,7 +242,7 @@ __global__ __launch_bounds__(512, 2) void plc_wgrad_kernel(const WgradArgs a) {
                 }
             }
             // input part at its unit index; dz part with each channel block padded to DZ_CB units
-            const int dst = u < G::IN_UNITS ? u : u + (u - G::IN_UNITS) / (WG_TH * 32) * (G::DZ_CB - WG_TH * 32);
+            const int dst = u < G::IN_UNITS ? u : u + (u - G::IN_UNITS) / (G::TH * 32) * (G::DZ_CB - G::TH * 32);
             if (u < G::IN_UNITS + G::DZ_UNITS) smem[buf * G::BUF_UNITS + dst] = v;
         }
     };
@@ -261,7 +266,7 @@ __global__ __launch_bounds__(512, 2) void plc_wgrad_kernel(const WgradArgs a) {
         // each transposing read next to its use and every MFMA then waits out an LDS round trip
         // (matrix pipe 44 % busy with two waves per SIMD); sched_barrier pins the order written
         // here, the compiler still derives the exact lgkmcnt waits.
-        constexpr int TOTAL = WG_TH * 2 * G::NT_W;
+        constexpr int TOTAL = G::TH * 2 * G::NT_W;
         constexpr int DEPTH = TOTAL < WG_PF_DEPTH ? TOTAL : WG_PF_DEPTH;
         constexpr int BR = DEPTH + 1, AR = DEPTH / G::NT_W + 2;
         bf16x8_t bq[BR], aq[AR];
@@ -292,7 +297,7 @@ __global__ __launch_bounds__(512, 2) void plc_wgrad_kernel(const WgradArgs a) {
             }
         } else {
 #pragma unroll
-            for (int ks = 0; ks < WG_TH * 2; ++ks) {
+            for (int ks = 0; ks < G::TH * 2; ++ks) {
                 const int row = ks >> 1, xk = (ks & 1) * 16;
                 const bf16x8_t af = frag(a_addr + (row * 32 + xk) * 16);
 #pragma unroll
