@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Benchmark of the ConvLSTM rollout hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--mode train|fwd] [--config c3|c2|c1|c4|p2]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--mode train|fwd] [--config c3|c2|c1|c4|c5|p2]
 
 One "step" = one pass of the hot path over one batch of synthetic, HBM-resident input:
   train (default): zero_grad -> Generator rollout forward -> CombinedLoss -> backward (BPTT)
@@ -31,6 +31,7 @@ CONFIGS = {
     "c2": (8, 10, 128, 128, 1),    # configs[1]
     "c3": (4, 10, 256, 256, 1),    # configs[2] per-GPU shard (the shape the metric is quoted on)
     "c4": (4, 20, 256, 256, 1),    # configs[3] per-GPU shard (generator only)
+    "c5": (1, 10, 512, 512, 1),    # configs[4] per-GPU shard, run in bf16 (no fp8 gate conv is built)
     "p2": (4, 10, 32, 32, 8),      # default.yaml-faithful x8 downscaling to 256x256
 }
 FLOP_PER_PX_FWD = 171104          # algorithmic forward FLOPs per output pixel per frame (scale 1, L=5)
