@@ -1,6 +1,8 @@
 """Edge geometries of the rollout (forward and parameter gradients) on the engine against the CPU
 oracle: single time step, tiny and one-pixel-wide grids, odd batch, 1 / 9 / 16 land-use channels,
-auxiliary maps at another resolution, with randomly initialised parameters (not the golden ones).
+auxiliary maps at another resolution, and the benchmark resolution (256x256 at scale 1 and through
+three upsample blocks), where the persistent kernels walk several tiles per workgroup; with
+randomly initialised parameters (not the golden ones).
 
 The oracle's fp32 path is pinned to the reference by the goldens; its bf16-storage emulation rounds
 where the engine rounds.  Bounds: forward <= 2e-2 * max|ref| vs fp32 and <= 4e-3 vs the emulation
@@ -22,6 +24,10 @@ CASES = [
     (2, 3, 6, 4, 2, 5, (7, 9)),      # one upsample block, aux maps at an unrelated resolution
     (1, 2, 5, 6, 4, 3, None),        # two upsample blocks
     (2, 2, 20, 70, 1, 5, None),      # wider than one 64-column strip of the one-channel weight gradient, ragged in both axes
+    # benchmark resolution: more tiles / strips than persistent workgroups, so every weight-gradient
+    # kernel walks several tiles per workgroup (double-buffered LDS, accumulators kept across tiles)
+    (2, 4, 256, 256, 1, 5, None),
+    (1, 2, 32, 32, 8, 5, None),      # the x8 downscaling configuration: three upsample blocks up to 256x256
 ]
 
 
