@@ -28,6 +28,7 @@ CASES = [
     # kernel walks several tiles per workgroup (double-buffered LDS, accumulators kept across tiles)
     (2, 4, 256, 256, 1, 5, None),
     (1, 2, 32, 32, 8, 5, None),      # the x8 downscaling configuration: three upsample blocks up to 256x256
+    (1, 20, 24, 40, 1, 5, None),     # the longest horizon of the benchmark configurations (T = 20)
 ]
 
 
