@@ -107,12 +107,14 @@ __global__ __launch_bounds__(256) void plc_loss_main_kernel(const LossArgs a) {
         float cur[V], up[V], dn[V], pv[V], nx[V];
         const bool has_up = y > 0, has_dn = y + 1 < Hh, has_pv = t > 0, has_nx = t + 1 < T;
         if constexpr (V == 4) {
+            // A neighbour that does not exist is replaced by the pixel's own address (its value is
+            // never used: every use below is guarded by the same has_* flag), so all loads are
+            // unconditional and in flight together instead of one round trip after another.
             const float4 c4 = *(const float4*)p;
-            const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-            const float4 u4 = has_up ? *(const float4*)(p - Wh) : z4;
-            const float4 d4 = has_dn ? *(const float4*)(p + Wh) : z4;
-            const float4 p4 = has_pv ? *(const float4*)(p - plane) : z4;
-            const float4 n4 = has_nx ? *(const float4*)(p + plane) : z4;
+            const float4 u4 = *(const float4*)(p - (has_up ? Wh : 0));
+            const float4 d4 = *(const float4*)(p + (has_dn ? Wh : 0));
+            const float4 p4 = *(const float4*)(p - (has_pv ? plane : 0));
+            const float4 n4 = *(const float4*)(p + (has_nx ? plane : 0));
             cur[0] = c4.x; cur[1] = c4.y; cur[2] = c4.z; cur[3] = c4.w;
             up[0] = u4.x; up[1] = u4.y; up[2] = u4.z; up[3] = u4.w;
             dn[0] = d4.x; dn[1] = d4.y; dn[2] = d4.z; dn[3] = d4.w;
@@ -122,15 +124,15 @@ __global__ __launch_bounds__(256) void plc_loss_main_kernel(const LossArgs a) {
 #pragma unroll
             for (int k = 0; k < V; ++k) {
                 cur[k] = p[k];
-                up[k] = has_up ? p[k - Wh] : 0.0f;
-                dn[k] = has_dn ? p[k + Wh] : 0.0f;
-                pv[k] = has_pv ? p[k - plane] : 0.0f;
-                nx[k] = has_nx ? p[k + plane] : 0.0f;
+                up[k] = p[k - (has_up ? Wh : 0)];
+                dn[k] = p[k + (has_dn ? Wh : 0)];
+                pv[k] = p[k - (has_pv ? plane : 0)];
+                nx[k] = p[k + (has_nx ? plane : 0)];
             }
         }
         const bool has_l = x0 > 0, has_r = x0 + V < Wh;
-        const float left = has_l ? p[-1] : 0.0f;
-        const float right = has_r ? p[V] : 0.0f;
+        const float left = p[has_l ? -1 : 0];
+        const float right = p[has_r ? V : 0];
         float g[V];
 #pragma unroll
         for (int k = 0; k < V; ++k) {
