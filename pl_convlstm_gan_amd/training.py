@@ -6,8 +6,9 @@ batch data parallelism over the GPUs of a node.
 The reference is single-device.  Data parallelism is new here: one process per GPU, each with
 its own batch shard; the only exchange is ONE all-reduce (RCCL over xGMI) of one flat fp32
 gradient buffer (85 889 floats for hidden [16,32] at scale 1), issued after backward and before
-``clip_grad_norm_`` so that the clip sees the global gradient, plus a 1-element all-reduce of
-the NaN flag so that every rank skips the same batches.  At 0.34 MB the gradient message is
+``clip_grad_norm_`` so that the clip sees the global gradient; the NaN flag that makes every rank
+skip the same batches travels as one more element of that buffer (device-side check) or as a
+1-element all-reduce before the backward pass (host-side check).  At 0.34 MB the gradient message is
 latency-bound, so it is sent as a single bucket with no overlap machinery.
 """
 from __future__ import annotations
@@ -27,14 +28,21 @@ class GradBucket:
         self.sizes = [p.numel() for p in self.params]
         self.flat: Optional[torch.Tensor] = None
 
-    def gather(self) -> torch.Tensor:
+    def gather(self, extra: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """``extra`` (1-D fp32) rides at the end of the buffer through the same all-reduce."""
         grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in self.params]
-        self.flat = torch.cat([g.reshape(-1) for g in grads])
+        parts = [g.reshape(-1) for g in grads]
+        if extra is not None:
+            parts.append(extra.reshape(-1).to(parts[0].dtype))
+        self.flat = torch.cat(parts)
         return self.flat
 
     def scatter(self):
-        for p, chunk in zip(self.params, self.flat.split(self.sizes)):
+        for p, chunk in zip(self.params, self.flat[:sum(self.sizes)].split(self.sizes)):
             p.grad = chunk.view_as(p)
+
+    def extra(self) -> torch.Tensor:
+        return self.flat[sum(self.sizes):]
 
 
 def _world(group=None) -> int:
@@ -103,20 +111,22 @@ def train_step(model, loss_module, optimizer, rain_lr, dem, lu, s_coords, s_valu
     guard = None
     if on_device:
         guard = loss.detach().reshape(1)
-        if _world(group) > 1:                        # a NaN on any rank poisons every rank's guard
-            flag = torch.isnan(guard).to(torch.float32)
-            _all_reduce(flag, dist.ReduceOp.MAX, group)
-            guard = torch.where(flag > 0, torch.full_like(guard, float("nan")), guard)
     elif any_rank_true(torch.isnan(loss.detach()), group):
         return loss, loss_dict, fake_hr, True
     loss.backward()
     params = list(clip_params if clip_params is not None else model.parameters())
     if _world(group) > 1 or not fused:
         bucket = GradBucket(params)
-        flat = bucket.gather()
+        # device mode: this rank's NaN flag rides in the gradient bucket, so the step has ONE
+        # collective; its mean is > 0 iff the loss of any rank is NaN, which poisons every rank's guard
+        share_flag = on_device and _world(group) > 1
+        flat = bucket.gather(torch.isnan(guard).to(torch.float32) if share_flag else None)
         all_reduce_mean_(flat, group)
+        if share_flag:
+            flag = bucket.extra()
+            guard = torch.where((flag > 0) | torch.isnan(flag), torch.full_like(guard, float("nan")), guard)
         if not fused:
-            clip_flat_(flat, max_norm)
+            clip_flat_(flat[:sum(bucket.sizes)], max_norm)
         bucket.scatter()
     if fused:
         optimizer.clip_and_step(params, max_norm, guard=guard)
