@@ -79,3 +79,24 @@ def test_drop_in_import_paths():
     y = add_coord_channels(torch.zeros(2, 1, 3, 4))
     assert y.shape == (2, 3, 3, 4)
     assert torch.equal(y[0, 1, :, 0], torch.linspace(0, 1, 3)) and torch.equal(y[0, 2, 0, :], torch.linspace(0, 1, 4))
+
+
+def test_grad_bucket_carries_an_extra_element():
+    """GradBucket.gather(extra): the extra values ride behind the gradients through the same flat
+    buffer (the device-side NaN flag of the data-parallel step) and scatter() ignores them."""
+    import torch
+    from pl_convlstm_gan_amd.training import GradBucket
+    torch.manual_seed(0)
+    params = [torch.nn.Parameter(torch.randn(3, 2)), torch.nn.Parameter(torch.randn(5))]
+    for p in params:
+        p.grad = torch.randn_like(p)
+    want = [p.grad.clone() for p in params]
+    bucket = GradBucket(params)
+    flat = bucket.gather(torch.tensor([1.0]))
+    assert flat.numel() == 6 + 5 + 1 and float(bucket.extra()) == 1.0
+    flat.mul_(0.5)                                   # what the all-reduce mean does, in place
+    bucket.scatter()
+    for p, w in zip(params, want):
+        assert p.grad.shape == p.shape and torch.equal(p.grad, w * 0.5)
+    assert float(bucket.extra()) == 0.5
+    assert GradBucket(params).gather().numel() == 11  # without an extra element nothing is appended
