@@ -2,6 +2,12 @@
 """Benchmark of the ConvLSTM rollout hot path on MI355X.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--mode train|fwd] [--config c3|c2|c1|c4|c5|p2]
+                    [--global-batch G]
+
+With --gpus N > 1 and no torchrun environment the script starts the N ranks itself (one process per
+GPU, `python -m torch.distributed.run --nproc-per-node N`) before anything touches a GPU, and fails
+at once, with a non-zero exit code, when the box has fewer than N GPUs or when the number of ranks it
+finds itself in disagrees with --gpus.
 
 One "step" = one pass of the hot path over one batch of synthetic, HBM-resident input:
   train (default): zero_grad -> Generator rollout forward -> CombinedLoss -> backward (BPTT)
@@ -14,8 +20,11 @@ only collective is the gradient all-reduce, per-GPU work is fixed (weak scaling)
 Rank 0 prints ONE JSON line.
 """
 import argparse
+import datetime
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -35,6 +44,7 @@ CONFIGS = {
     "p2": (4, 10, 32, 32, 8),      # default.yaml-faithful x8 downscaling to 256x256
 }
 FLOP_PER_PX_FWD = 171104          # algorithmic forward FLOPs per output pixel per frame (scale 1, L=5)
+FWD_BYTES_PER_PX = 804            # algorithmic forward tensor traffic per pixel per frame: 402 elements as bf16
 CELL2_FLOP_PER_PX = 2 * 55296     # cell-2 gate conv: (16+32)*9*128 MACs per pixel
 CELL2_BYTES_PER_PX = 416          # x 32 + h 64 + c 128 read, h' 64 + c' 128 written (bf16 h, fp32 c)
 PEAK_BF16 = 2.5e15                # dense bf16 MFMA peak of MI355X, FLOP/s
@@ -154,6 +164,17 @@ def cpu_baseline(mode, B, T, H, W, s, params):
             "sample": f"B={Bc} of the per-GPU workload (T={T}, {H * s}x{W * s}), fp32 PyTorch-CPU oracle {what}, best of 3"}
 
 
+def launch_ranks(n, argv):
+    """Start n ranks of this script under torch.distributed.run (a child process; nothing here has
+    touched a GPU yet) and return its exit code."""
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    return subprocess.call(cmd)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -161,26 +182,44 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--mode", default="train", choices=["train", "fwd"])
     ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
+    ap.add_argument("--global-batch", type=int, default=0,
+                    help="total batch over all ranks (strong-scaling anchor, e.g. 32 for BASELINE configs[2]); "
+                         "default: the config's per-GPU batch on every rank (weak scaling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+
+    backend = os.environ.get("PLC_BENCH_BACKEND", "nccl")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # not under torchrun: become the launcher.  device_count() does not initialise the GPU.
+        have = torch.cuda.device_count()
+        if backend == "nccl" and have < args.gpus:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but this box has {have} GPU(s); nothing was run")
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; nothing was run")
     # PLC_BENCH_BACKEND=gloo is a rehearsal aid: several ranks share one GPU to exercise the
     # multi-process control flow on a single-GPU box (numbers from it are meaningless)
-    backend = os.environ.get("PLC_BENCH_BACKEND", "nccl")
+    if backend == "nccl" and world > torch.cuda.device_count():
+        raise SystemExit(f"bench.py: {world} ranks but {torch.cuda.device_count()} GPU(s): one rank per GPU")
     dev_index = local_rank % max(torch.cuda.device_count(), 1) if backend != "nccl" else local_rank
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # a collective that does not complete within the timeout aborts the process (non-zero exit)
+        # instead of hanging until the job's lease runs out
+        patience = datetime.timedelta(seconds=int(os.environ.get("PLC_BENCH_PG_TIMEOUT", "180")))
         if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+            os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "1")
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device, timeout=patience)
         else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+            dist.init_process_group(backend, rank=rank, world_size=world, timeout=patience)
 
     def dbg(msg):
         if os.environ.get("PLC_BENCH_DEBUG"):
@@ -192,6 +231,11 @@ def main():
     from pl_convlstm_gan_amd.training import train_step
 
     B, T, H, W, s = CONFIGS[args.config]
+    scaling = "weak"
+    if args.global_batch:
+        if args.global_batch % world:
+            raise SystemExit(f"bench.py: --global-batch {args.global_batch} does not divide over {world} ranks")
+        B, scaling = args.global_batch // world, "strong"
     torch.manual_seed(0)                       # identical initial weights on every rank
     model = Generator(hidden_dims=[16, 32], lu_channels=5, scale_factor=s)
     rain, dem, lu, coords, values = synthetic(B, T, H, W, s, 1234 + rank, device)
@@ -239,8 +283,9 @@ def main():
 
     main_fn = step_train if args.mode == "train" else step_fwd
     dt = timed(main_fn, args.steps, args.warmup)
-    dt_fwd = timed(step_fwd, max(5, args.steps // 2), 2) if args.mode == "train" else dt
-    n_fwd = max(5, args.steps // 2) if args.mode == "train" else args.steps
+    # the forward-only leg of a train run gets the same warm-up and step count as the train leg
+    dt_fwd = timed(step_fwd, args.steps, args.warmup) if args.mode == "train" else dt
+    n_fwd = args.steps
 
     if rank == 0:
         frames = world * B * T * args.steps
@@ -250,7 +295,7 @@ def main():
             "metric": "predicted frames/sec (whole node), BxTxCx256x256" if args.config in ("c3", "c4", "p2")
                       else "predicted frames/sec (whole node)",
             "value": frames / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"{args.config}: {what}, B={B}/GPU, T={T}, {H}x{W} -> {H * s}x{W * s}, 1 channel, "
                                    f"hidden [16,32], L=5, scale_factor={s}, {N_STATIONS} stations",
@@ -258,6 +303,15 @@ def main():
                        "parallelism": f"dp{world} (batch sharded; one flat-gradient all-reduce per step)"},
             "fwd_frames_per_s": world * B * T * n_fwd / dt_fwd,
         }
+        # whole-path view next to the per-kernel rooflines: algorithmic forward FLOPs per frame
+        # (171 104 per output pixel at scale 1; a train step is 3x: data + weight gradients) and, for the
+        # forward, the algorithmic bf16 tensor traffic per frame (402 elements per pixel) over the step time
+        if s == 1:
+            px = H * W
+            fwd_flop = FLOP_PER_PX_FWD * px * world * B * T
+            res["step_mfma_frac"] = (3 if args.mode == "train" else 1) * fwd_flop / (dt / args.steps) / (world * PEAK_BF16)
+            res["fwd_mfma_frac"] = fwd_flop / (dt_fwd / n_fwd) / (world * PEAK_BF16)
+            res["fwd_hbm_frac"] = FWD_BYTES_PER_PX * px * world * B * T / (dt_fwd / n_fwd) / (world * PEAK_HBM)
         # dominant kernel: cell-2 gate conv, one launch per timestep
         tk = time_cell2_kernel(B, H, W, device)
         flops = CELL2_FLOP_PER_PX * B * H * W

@@ -46,10 +46,10 @@ def _param_list(model):
 class _RolloutFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, rain_lr, dem, lu, input_grid_size, *params):
-        out, desc, ws = model._forward_impl(rain_lr, dem, lu, input_grid_size, save_for_backward=True)
+        out, desc, ws = model._forward_impl(rain_lr, dem, lu, input_grid_size, True, params)
         ctx.model = model
         ctx.desc = desc
-        ctx.ws = ws                      # saved activations live in the forward workspace
+        ctx.ws = ws                      # saved activations live in the forward workspace (+ the bound parameters)
         ctx.keep = (rain_lr, dem, lu)    # the descriptor holds raw pointers into these
         ctx.n_blocks = len(model.upsample_blocks)
         ctx.shapes = [p.shape for p in params]
@@ -88,7 +88,6 @@ class _RolloutFn(torch.autograd.Function):
         return (None, None, None, None, None) + tuple(grads)
 
 
-def rollout_with_grad(model, rain_lr, dem, lu, input_grid_size):
-    # the lazy blocks must exist before the parameter list is taken
-    model._geometry(rain_lr.shape[-2], rain_lr.shape[-1], input_grid_size, rain_lr.device)
-    return _RolloutFn.apply(model, rain_lr, dem, lu, input_grid_size, *_param_list(model))
+def rollout_with_grad(model, rain_lr, dem, lu, input_grid_size, params):
+    """``params``: _param_list(model) on the inputs' device (the lazy blocks exist by now)."""
+    return _RolloutFn.apply(model, rain_lr, dem, lu, input_grid_size, *params)

@@ -196,11 +196,19 @@ static PlcTensor tens(const void* p, long long si, long long so) {
     return t;
 }
 
-// Number of CUs of the current device (an immutable device attribute, looked up once per device).
+// Host-side caches of immutable per-device facts (the only process-wide state the library keeps;
+// entries are written once with the same value by whichever thread gets there first).
+static int current_device() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return -1;
+    return dev;
+}
+
+// Number of CUs of the current device.
 static int cu_count() {
     static int cached[64] = {0};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    const int dev = current_device();
+    if (dev < 0) return 256;
     if (cached[dev] == 0) {
         int n = 0;
         if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
@@ -209,13 +217,26 @@ static int cu_count() {
     return cached[dev];
 }
 
+// Raises a kernel's dynamic-LDS limit once per (kernel, device) instead of on every launch; `done` is
+// the per-instantiation flag array of the caller.
+static int ensure_lds_limit(const void* kern, int lds, bool (&done)[64]) {
+    const int dev = current_device();
+    if (dev >= 0 && done[dev]) return PLC_OK;
+    PLC_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    if (dev >= 0) done[dev] = true;
+    return PLC_OK;
+}
+
 // One instantiation at a fixed tile height TH (and K split).
 template <int NCB0, int NCB1, int NMT, int KS, int STAGE, int EPI, int TH, int KSPLIT = 1>
 static int launch_conv_th(ConvArgs a, int n_img, int n_mgroups, hipStream_t st) {
     constexpr int lds = plc_conv_lds_bytes<NCB0 + NCB1, KS, TH, KSPLIT, STAGE>();
     auto kern = plc_conv_mfma_kernel<NCB0, NCB1, NMT, KS, STAGE, EPI, TH, KSPLIT>;
-    if (lds > 65536)
-        PLC_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    if (lds > 65536) {
+        static bool lds_raised[64] = {false};
+        int rc = ensure_lds_limit((const void*)kern, lds, lds_raised);
+        if (rc) return rc;
+    }
     a.tiles_x = cdiv(a.W, 32);
     a.tiles_y = cdiv(a.H, TH);
     a.n_tiles = n_img * a.tiles_x * a.tiles_y;

@@ -16,8 +16,8 @@
 // latency nor the LDS read count is what bounds it; the parallel prefetch pays only where a tile
 // takes many loads per thread (the gated staging: 174 -> 136 us).
 template <int NCB0, int NCB1, int MT, int KS>
-static constexpr int wgrad_max_blocks() {
-    return WgradGeom<NCB0 + NCB1, MT, KS>::LDS_BYTES <= 80 * 1024 ? 512 : 256;
+static int wgrad_max_blocks() {
+    return (WgradGeom<NCB0 + NCB1, MT, KS>::LDS_BYTES <= 80 * 1024 ? 2 : 1) * cu_count();
 }
 
 template <int NCB0, int NCB1, int MT, int KS>
@@ -82,10 +82,14 @@ static int launch_wgrad(ConvArgs in, PlcTensor dz, int mcb_valid, int n_img, Sla
     a.rows_valid = cout;
     a.n_tiles = n_img * a.in.tiles_x * a.in.tiles_y;
     a.slab = slab;
-    constexpr int max_blocks = wgrad_max_blocks<NCB0, NCB1, MT, KS>();
+    const int max_blocks = wgrad_max_blocks<NCB0, NCB1, MT, KS>();
     const int grid = a.n_tiles < max_blocks ? a.n_tiles : max_blocks;
     auto kern = plc_wgrad_kernel<NCB0, NCB1, MT, KS, STAGE>;
-    PLC_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES));
+    {
+        static bool lds_raised[64] = {false};
+        int rc = ensure_lds_limit((const void*)kern, G::LDS_BYTES, lds_raised);
+        if (rc) return rc;
+    }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), G::LDS_BYTES, st, a);
     PLC_HIP(hipGetLastError());
     FinalizeJob jb;

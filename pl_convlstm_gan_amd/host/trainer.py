@@ -38,6 +38,29 @@ def _rank_world():
     return 0, 1
 
 
+def shard_bounds(n, rank, world):
+    """[lo, hi) of rank's slice of a batch of n samples, or None when the batch has fewer samples than
+    ranks.  Every rank sees the same n, so all take the same decision without talking: a short batch is
+    skipped by ALL ranks (a rank with an empty slice would otherwise miss the gradient all-reduce the
+    others are waiting in)."""
+    if n < world:
+        return None
+    return rank * n // world, (rank + 1) * n // world
+
+
+def mean_over_ranks(x):
+    """Mean of a host scalar over the ranks (identity for one process): what feeds the LR scheduler,
+    early stopping and the best-model decision must be the same number on every rank."""
+    rank, world = _rank_world()
+    if world == 1:
+        return float(x)
+    t = torch.tensor([float(x)], dtype=torch.float64)
+    if dist.get_backend() == "nccl":
+        t = t.cuda()
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return float(t.item()) / world
+
+
 class Trainer:
     def __init__(self, config_name="default"):
         self.config = load_config(config_name)
@@ -107,13 +130,15 @@ class Trainer:
         return tuple(t.to(self.device) for t in batch)
 
     def _shard(self, batch):
-        """This rank's slice of a batch (data parallelism; identity for a single process)."""
+        """This rank's slice of a batch (data parallelism; identity for a single process), or None
+        when the batch is shorter than the number of ranks and is skipped by all of them."""
         rank, world = _rank_world()
         if world == 1:
             return batch
-        n = batch[0].shape[0]
-        lo, hi = rank * n // world, (rank + 1) * n // world
-        return tuple(t[lo:hi] for t in batch)
+        bounds = shard_bounds(batch[0].shape[0], rank, world)
+        if bounds is None:
+            return None
+        return tuple(t[bounds[0]:bounds[1]] for t in batch)
 
     # ------------------------------------------------------------------ evaluation
     def compute_station_rmse(self, fake_hr, s_coords, s_values, scale_factor=1.0):
@@ -155,9 +180,10 @@ class Trainer:
         sums = {k: [] for k in ("total", "point", "conserve", "smooth", "temporal")}
         last = (None, None, None, None)
         for i, batch in enumerate(self.train_loader):
-            lr, dem, lu, s_coords, s_values = self._shard(self._to_device(batch))
-            if lr.shape[0] == 0:
+            shard = self._shard(self._to_device(batch))
+            if shard is None:          # fewer samples than ranks: every rank skips (same decision everywhere)
                 continue
+            lr, dem, lu, s_coords, s_values = shard
             loss, parts, fake_hr, skipped = train_step(
                 self.model, self.loss_module, self.optimizer, lr, dem, lu, s_coords, s_values,
                 max_norm=self.config.training.grad_clip_norm, forward_kwargs=self._forward_kwargs(),
@@ -187,16 +213,21 @@ class Trainer:
         path = os.path.join(self.output_dir, "best_model.pth")
         if os.path.exists(path):
             os.remove(path)
-        torch.save({"epoch": epoch, "model_state_dict": self.model.state_dict(),
+        # plain Python numbers only, so the file loads with torch.load(weights_only=True)
+        history = {k: [float(x) if isinstance(x, (float, np.floating)) else int(x) for x in v]
+                   for k, v in self.history.items()}
+        sched = {k: (float(v) if isinstance(v, np.floating) else v) for k, v in self.scheduler.state_dict().items()}
+        torch.save({"epoch": int(epoch), "model_state_dict": self.model.state_dict(),
                     "optimizer_state_dict": self.optimizer.state_dict(),
-                    "scheduler_state_dict": self.scheduler.state_dict(), "rmse": rmse, "history": self.history}, path)
+                    "scheduler_state_dict": sched, "rmse": float(rmse), "history": history}, path)
         print(f"New best model saved: epoch {epoch + 1}, RMSE {rmse:.4f}")
 
     def resume(self, path):
         """Load a checkpoint written by ``train`` (not in the reference).  Needs setup_model first; the
         lazy upsample blocks are materialised from the checkpoint's keys."""
         from ..models import UpsampleBlock
-        ck = torch.load(path, map_location=self.device, weights_only=False)
+        # weights_only: nothing in the file is executed (a checkpoint may come from a third party)
+        ck = torch.load(path, map_location=self.device, weights_only=True)
         n_blocks = len({k.split(".")[1] for k in ck["model_state_dict"] if k.startswith("upsample_blocks.")})
         if self.model.upsample_blocks is None:
             self.model.upsample_blocks = torch.nn.ModuleList(
@@ -216,14 +247,16 @@ class Trainer:
         rank = _rank_world()[0]
         for epoch in range(start_epoch, self.config.training.epochs):
             rmses, at, truth, s_coords, inside, avg = self.train_epoch(epoch, T)
-            train_rmse = float(np.mean(rmses)) if rmses else float("nan")
+            # every rank trained on its own shards: the epoch figures that feed the scheduler, early
+            # stopping and the best-model decision are averaged over ranks so that all ranks decide alike
+            train_rmse = mean_over_ranks(float(np.mean(rmses)) if rmses else float("nan"))
             self.history["epoch"].append(epoch)
             for k in ("total", "point", "conserve", "smooth", "temporal"):
-                self.history[f"{k}_loss"].append(avg[k])
+                self.history[f"{k}_loss"].append(mean_over_ranks(avg[k]))
             self.history["rmse"].append(train_rmse)
             self.history["learning_rate"].append(self.optimizer.param_groups[0]["lr"])
             val = self.validate()
-            current = val["rmse"] if val else train_rmse
+            current = float(val["rmse"]) if val else train_rmse     # validation runs whole on every rank: identical
             if rank == 0:
                 print(f"Epoch {epoch} | Train RMSE: {train_rmse:.4f}" +
                       (f" | Val Loss: {val['loss']:.4f} | Val RMSE: {val['rmse']:.4f}" if val else ""))

@@ -39,11 +39,22 @@ class ConvLSTMCell(nn.Module):
     def forward(self, x, h_cur, c_cur):
         if self.conv.kernel_size != (3, 3):
             raise NotImplementedError("only kernel_size=3 is compiled")
-        if torch.is_grad_enabled() and any(t.requires_grad for t in (x, h_cur, c_cur, self.conv.weight)):
+        weight, bias = self.conv.weight, self.conv.bias
+        home = x.device
+        if not x.is_cuda:
+            # CPU-resident caller (the reference's tests build everything on the CPU): the operands are
+            # staged onto the GPU, the HIP kernel runs there, the results are copied back.  No CPU
+            # arithmetic exists; .to() is differentiable, so gradients find their way home.
+            dev = ops.staging_device()
+            x, h_cur, c_cur = x.to(dev), h_cur.to(dev), c_cur.to(dev)
+        if weight.device != x.device:
+            weight, bias = weight.to(x.device), None if bias is None else bias.to(x.device)
+        if torch.is_grad_enabled() and any(t.requires_grad for t in (x, h_cur, c_cur, weight)):
             from .autograd import cell_with_grad
-            return cell_with_grad(x, h_cur, c_cur, self.conv.weight, self.conv.bias)
-        return ops.convlstm_cell_forward(x, h_cur, c_cur, self.conv.weight.detach(),
-                                         None if self.conv.bias is None else self.conv.bias.detach())
+            h2, c2 = cell_with_grad(x, h_cur, c_cur, weight, bias)
+        else:
+            h2, c2 = ops.convlstm_cell_forward(x, h_cur, c_cur, weight.detach(), None if bias is None else bias.detach())
+        return h2.to(home), c2.to(home)
 
 
 class UpsampleBlock(nn.Module):
@@ -175,8 +186,7 @@ class Generator(nn.Module):
             raise NotImplementedError("the engine is built for in_channels=1 (rain only)")
         if self._dem_channels != 1 or dem.shape[1] != 1:
             raise NotImplementedError("the engine is built for dem_channels=1")
-        device = rain_lr.device
-        n_blocks, remaining, fH, fW = self._geometry(H, W, input_grid_size, device)
+        n_blocks, remaining, fH, fW = self._geometry(H, W, input_grid_size, next(self.parameters()).device)
         if lu.shape[1] != self.lu_channels or self.lu_channels < 1:
             raise RuntimeError(
                 f"lu has {lu.shape[1]} channels but the model was built with lu_channels={self.lu_channels}")
@@ -208,23 +218,28 @@ class Generator(nn.Module):
         d.save_for_backward = 1 if save_for_backward else 0
         return d, (fH, fW)
 
-    def _bind(self, d, rain_lr, dem, lu, out):
+    def _bind(self, d, rain_lr, dem, lu, out, params):
+        """``params``: the parameter tensors in autograd._param_list order, on the inputs' device (the
+        module's own parameters, or their staged copies when the module lives on the CPU)."""
         row, col = self._tables(d.H, d.W, rain_lr.device)
         d.rain, d.dem, d.lu = rain_lr.data_ptr(), dem.data_ptr(), lu.data_ptr()
         d.row_tab, d.col_tab = row.data_ptr(), col.data_ptr()
-        P = lambda t: t.detach().contiguous().data_ptr()  # noqa: E731  (parameters are contiguous already)
-        d.init_w, d.init_b = P(self.init_conv.weight), P(self.init_conv.bias)
-        d.cell1_w, d.cell1_b = P(self.cell1.conv.weight), P(self.cell1.conv.bias)
-        d.cell2_w, d.cell2_b = P(self.cell2.conv.weight), P(self.cell2.conv.bias)
-        d.dem0_w, d.dem0_b = P(self.dem_attn.conv[0].weight), P(self.dem_attn.conv[0].bias)
-        d.dem2_w, d.dem2_b = P(self.dem_attn.conv[2].weight), P(self.dem_attn.conv[2].bias)
-        d.lu0_w, d.lu0_b = P(self.lu_attn.conv[0].weight), P(self.lu_attn.conv[0].bias)
-        d.lu2_w, d.lu2_b = P(self.lu_attn.conv[2].weight), P(self.lu_attn.conv[2].bias)
-        for k, blk in enumerate(self.upsample_blocks):
-            d.up_w[k], d.up_b[k] = P(blk.conv.weight), P(blk.conv.bias)
-        d.post0_w, d.post0_b = P(self.post_process[0].weight), P(self.post_process[0].bias)
-        d.post2_w, d.post2_b = P(self.post_process[2].weight), P(self.post_process[2].bias)
+        keep = [t.detach().contiguous() for t in params]      # (parameters are contiguous already)
+        it = iter(keep)
+        P = lambda: next(it).data_ptr()  # noqa: E731
+        d.init_w, d.init_b = P(), P()
+        d.cell1_w, d.cell1_b = P(), P()
+        d.cell2_w, d.cell2_b = P(), P()
+        d.dem0_w, d.dem0_b = P(), P()
+        d.dem2_w, d.dem2_b = P(), P()
+        d.lu0_w, d.lu0_b = P(), P()
+        d.lu2_w, d.lu2_b = P(), P()
+        for k in range(len(self.upsample_blocks)):
+            d.up_w[k], d.up_b[k] = P(), P()
+        d.post0_w, d.post0_b = P(), P()
+        d.post2_w, d.post2_b = P(), P()
         d.out = out.data_ptr()
+        return keep
 
     def _workspace(self, d, device, fresh=False):
         L = _lib.lib()
@@ -258,24 +273,39 @@ class Generator(nn.Module):
 
     def forward(self, rain_lr, dem, lu, input_grid_size=None):
         """rain_lr [B,T,1,H,W], dem [B,1,Hd,Wd], lu [B,L,Hl,Wl] -> [B,T,1,Hh,Wh] (fp32)."""
+        from .autograd import _param_list, rollout_with_grad
+        if torch.is_grad_enabled() and any(isinstance(t, torch.Tensor) and t.requires_grad for t in (rain_lr, dem, lu)):
+            # the reference's autograd would return these; the engine's backward pass does not form them
+            raise NotImplementedError("gradients with respect to rain_lr / dem / lu are not computed by the engine: "
+                                      "detach the inputs (parameter gradients are available)")
+        home = rain_lr.device if isinstance(rain_lr, torch.Tensor) else None
+        if isinstance(rain_lr, torch.Tensor) and not rain_lr.is_cuda:
+            # CPU-resident caller (the reference's test/test_model.py builds model and inputs on the
+            # CPU): inputs and parameters are staged onto the GPU, the HIP rollout runs there and the
+            # result is copied back.  There is no CPU arithmetic path; without a GPU this raises.
+            dev = ops.staging_device()
+            rain_lr, dem, lu = rain_lr.to(dev), dem.to(dev), lu.to(dev)
         rain_lr = ops._require_dev(rain_lr, "rain_lr")
         dem = ops._require_dev(dem, "dem")
         lu = ops._require_dev(lu, "lu")
-        for prm in self.parameters():
-            if not prm.is_cuda:
-                raise RuntimeError("Generator parameters are not on the GPU: call .to('cuda') first")
-            break
-        needs_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        dev = rain_lr.device
+        # the lazy blocks are created where the module lives, from the caller's RNG, as in the reference
+        module_dev = next(self.parameters()).device
+        self._geometry(rain_lr.shape[-2], rain_lr.shape[-1], input_grid_size, module_dev)
+        own = _param_list(self)
+        needs_grad = torch.is_grad_enabled() and any(p.requires_grad for p in own)
+        params = [p if p.device == dev else p.to(dev) for p in own]   # .to() is differentiable
         if needs_grad:
-            from .autograd import rollout_with_grad
-            return rollout_with_grad(self, rain_lr, dem, lu, input_grid_size)
-        return self._forward_impl(rain_lr, dem, lu, input_grid_size, save_for_backward=False)[0]
+            out = rollout_with_grad(self, rain_lr, dem, lu, input_grid_size, params)
+        else:
+            out = self._forward_impl(rain_lr, dem, lu, input_grid_size, False, [p.detach() for p in params])[0]
+        return out if out.device == home else out.to(home)
 
-    def _forward_impl(self, rain_lr, dem, lu, input_grid_size, save_for_backward):
+    def _forward_impl(self, rain_lr, dem, lu, input_grid_size, save_for_backward, params):
         d, _ = self._describe(rain_lr, dem, lu, input_grid_size, save_for_backward)
         out = torch.empty((d.B, d.T, 1, d.out_H, d.out_W), dtype=torch.float32, device=rain_lr.device)
         ws = self._workspace(d, rain_lr.device, fresh=save_for_backward)
-        self._bind(d, rain_lr, dem, lu, out)
+        keep = self._bind(d, rain_lr, dem, lu, out, params)
         rc = _lib.lib().plc_generator_rollout_fwd(C.byref(d), ops._stream())
         _lib.check(rc, "plc_generator_rollout_fwd")
-        return out, d, ws
+        return out, d, (ws, keep)

@@ -28,6 +28,15 @@ def _require_dev(t: torch.Tensor, name: str) -> torch.Tensor:
     return t.contiguous()
 
 
+def staging_device() -> torch.device:
+    """Where CPU-resident operands are staged for the HIP kernels.  There is no CPU arithmetic path:
+    without a GPU this raises."""
+    if not torch.cuda.is_available():
+        raise RuntimeError("the ConvLSTM engine runs on MI355X (HIP) only and no GPU is visible; "
+                           "there is no CPU fallback")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
 def workspace(nbytes: int, device) -> torch.Tensor:
     return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
 

@@ -30,6 +30,9 @@ class GradBucket:
 
     def gather(self, extra: Optional[torch.Tensor] = None) -> torch.Tensor:
         """``extra`` (1-D fp32) rides at the end of the buffer through the same all-reduce."""
+        # a parameter without a gradient contributes zeros to the exchange; scatter() leaves it
+        # without one if no rank had any, so the optimizer skips it as torch.optim would
+        self.had_grad = [p.grad is not None for p in self.params]
         grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in self.params]
         parts = [g.reshape(-1) for g in grads]
         if extra is not None:
@@ -37,9 +40,12 @@ class GradBucket:
         self.flat = torch.cat(parts)
         return self.flat
 
-    def scatter(self):
-        for p, chunk in zip(self.params, self.flat[:sum(self.sizes)].split(self.sizes)):
-            p.grad = chunk.view_as(p)
+    def scatter(self, keep_none: bool = True):
+        """Point every ``p.grad`` at its slice of the flat buffer.  ``keep_none``: parameters that had
+        no gradient at gather() time get ``None`` back (only valid when every rank agrees on which
+        parameters those are, i.e. the same graph on every rank -- the case here)."""
+        for p, had, chunk in zip(self.params, self.had_grad, self.flat[:sum(self.sizes)].split(self.sizes)):
+            p.grad = chunk.view_as(p) if (had or not keep_none) else None
 
     def extra(self) -> torch.Tensor:
         return self.flat[sum(self.sizes):]
@@ -47,6 +53,12 @@ class GradBucket:
 
 def _world(group=None) -> int:
     return dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+
+
+def _dp_active(group=None) -> bool:
+    """A process group exists: the gradient exchange runs (also for a group of one rank, where it is
+    the identity -- that is how the RCCL path is exercised on a one-GPU box)."""
+    return dist.is_available() and dist.is_initialized()
 
 
 def _all_reduce(t: torch.Tensor, op, group=None) -> torch.Tensor:
@@ -67,6 +79,23 @@ def all_reduce_mean_(flat: torch.Tensor, group=None) -> torch.Tensor:
     if w > 1:
         _all_reduce(flat, dist.ReduceOp.SUM, group)
         flat.mul_(1.0 / w)
+    return flat
+
+
+def all_reduce_weighted_mean_(flat: torch.Tensor, n_local: int, group=None) -> torch.Tensor:
+    """Sample-weighted mean over ranks, in place: ``flat`` must carry one spare LAST element; every rank
+    scales its buffer by its own sample count, the spare element carries that count through the same
+    SUM all-reduce, and the sum is divided by the total (a device scalar: no host sync).  With equal
+    shards this equals the plain mean; with unequal ones it is the per-sample mean of the global
+    batch (a mean of per-rank means would overweight the short shard)."""
+    if _world(group) > 1:
+        flat.mul_(float(n_local))
+        flat[-1] = float(n_local)
+        _all_reduce(flat, dist.ReduceOp.SUM, group)
+        total = flat[-1].clone()
+        flat.div_(total)
+    elif _dp_active(group):
+        _all_reduce(flat, dist.ReduceOp.SUM, group)     # one rank: the sum is the buffer itself
     return flat
 
 
@@ -115,15 +144,22 @@ def train_step(model, loss_module, optimizer, rain_lr, dem, lu, s_coords, s_valu
         return loss, loss_dict, fake_hr, True
     loss.backward()
     params = list(clip_params if clip_params is not None else model.parameters())
-    if _world(group) > 1 or not fused:
+    if _dp_active(group) or not fused:
         bucket = GradBucket(params)
+        multi = _dp_active(group)
         # device mode: this rank's NaN flag rides in the gradient bucket, so the step has ONE
-        # collective; its mean is > 0 iff the loss of any rank is NaN, which poisons every rank's guard
-        share_flag = on_device and _world(group) > 1
-        flat = bucket.gather(torch.isnan(guard).to(torch.float32) if share_flag else None)
-        all_reduce_mean_(flat, group)
+        # collective; its mean is > 0 iff the loss of any rank is NaN, which poisons every rank's guard.
+        # The last element is the spare one of the sample-weighted mean (this rank's sample count).
+        share_flag = on_device and multi
+        extra = []
         if share_flag:
-            flag = bucket.extra()
+            extra.append(torch.isnan(guard).to(torch.float32).reshape(1))
+        if multi:
+            extra.append(torch.zeros(1, dtype=torch.float32, device=rain_lr.device))
+        flat = bucket.gather(torch.cat(extra) if extra else None)
+        all_reduce_weighted_mean_(flat, int(rain_lr.shape[0]), group)
+        if share_flag:
+            flag = bucket.extra()[:1]
             guard = torch.where((flag > 0) | torch.isnan(flag), torch.full_like(guard, float("nan")), guard)
         if not fused:
             clip_flat_(flat[:sum(bucket.sizes)], max_norm)

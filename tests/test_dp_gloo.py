@@ -116,3 +116,63 @@ def test_bucket_roundtrip_and_clip():
     coef = min(1.0, 0.5 / (float(total) + 1e-6))
     for p, g in zip(m.parameters(), ref):
         assert torch.allclose(p.grad, g * coef, atol=1e-7)
+
+
+def _worker_uneven(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from pl_convlstm_gan_amd.host.trainer import mean_over_ranks, shard_bounds
+    from pl_convlstm_gan_amd.losses import CombinedLoss
+    from pl_convlstm_gan_amd.training import train_step
+    torch.manual_seed(0)
+    model = TinyRollout()
+    opt = torch.optim.Adam(model.parameters(), lr=5e-4)
+    # a batch of 3 over 2 ranks: shards of 1 and 2 samples, sliced the way the Trainer slices
+    batch = _batch(30, B=3)
+    lo, hi = shard_bounds(3, rank, world)
+    shard = tuple(t[lo:hi] for t in batch)
+    train_step(model, CombinedLoss(), opt, *shard, max_norm=0.5)
+    # a batch of 1 is shorter than the world: every rank must take the same "skip" decision
+    short = shard_bounds(1, rank, world)
+    torch.save({"p": [p.detach().clone() for p in model.parameters()], "n": hi - lo, "short": short is None,
+                "mean": mean_over_ranks(float(rank + 1))}, os.path.join(out_dir, f"rank{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_dp_uneven_shards_give_the_per_sample_mean(tmp_path):
+    """Shards of unequal size: the exchanged gradient is the per-sample mean of the global batch (each
+    rank weighted by its sample count), i.e. the step equals a single-process step on the whole batch;
+    a batch shorter than the world is skipped by every rank; epoch scalars are averaged over ranks."""
+    world = 2
+    mp.spawn(_worker_uneven, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r = [torch.load(tmp_path / f"rank{i}.pt", weights_only=True) for i in range(world)]
+    assert sorted(x["n"] for x in r) == [1, 2]
+    assert r[0]["short"] and r[1]["short"]
+    assert r[0]["mean"] == r[1]["mean"] == 1.5
+    for a, b in zip(r[0]["p"], r[1]["p"]):
+        assert torch.equal(a, b)
+    from pl_convlstm_gan_amd.losses import CombinedLoss
+    torch.manual_seed(0)
+    model = TinyRollout()
+    opt = torch.optim.Adam(model.parameters(), lr=5e-4)
+    rain, dem, lu, coords, values = _batch(30, B=3)
+    loss, _ = CombinedLoss()(model(rain, dem, lu), rain, coords, values, 1.0)
+    loss.backward()
+    torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=0.5)
+    opt.step()
+    for p, q in zip(model.parameters(), r[0]["p"]):
+        assert torch.allclose(p.detach(), q, atol=1e-7, rtol=1e-5)
+
+
+def test_bucket_keeps_missing_gradients_missing():
+    """A parameter without a gradient rides through the exchange as zeros and comes back without one,
+    so the optimizer skips it exactly as torch.optim would."""
+    from pl_convlstm_gan_amd.training import GradBucket
+    m = TinyRollout()
+    m.conv.weight.grad = torch.ones_like(m.conv.weight)
+    b = GradBucket(m.parameters())
+    flat = b.gather()
+    assert flat.numel() == sum(p.numel() for p in m.parameters())
+    b.scatter()
+    assert m.conv.weight.grad is not None and m.conv.bias.grad is None and m.gate.weight.grad is None

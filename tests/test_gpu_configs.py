@@ -1,0 +1,122 @@
+"""The benchmark configurations at their own sizes on the GPU (called through the C ABI):
+
+  c2  128x128, T=10, B=8 on one GPU      forward + parameter gradients vs the oracle at B=2;
+                                         bit-exact repeatability / batch independence at B=8
+  c4  256x256, T=20, B=4 per GPU         full-size properties (repeatability, causality, batch
+                                         independence), forward and gradients vs the oracle at B=1, T=20
+  c5  512x512, T=10, B=1 per GPU         forward vs the oracle at T=2, gradients at T=2, properties at T=10
+                                         (arithmetic: bf16 here; the fp8 gate conv has its own tests)
+
+Bounds are those of test_gpu_parity_fwd.py / test_gpu_edge_cases.py: forward <= 2e-2 * max|ref| vs
+the fp32 oracle and <= 4e-3 vs its bf16-storage emulation; gradients <= 3e-2 (max and L2) vs the
+emulation.  The oracle's fp32 path is pinned to the reference by the golden files."""
+import pytest
+import torch
+
+from oracle import cpu_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def relmax(a, b):
+    return float((a - b).abs().max()) / max(float(b.abs().max()), 1e-20)
+
+
+def rel_l2(a, b):
+    return float((a - b).norm()) / max(float(b.norm()), 1e-20)
+
+
+def synthetic(B, T, H, W, seed):
+    g = torch.Generator().manual_seed(seed)
+    rain = 10 * torch.rand(B, T, 1, H, W, generator=g) * (torch.rand(B, T, 1, H, W, generator=g) > 0.7)
+    dem = torch.rand(B, 1, H, W, generator=g)
+    lu = torch.nn.functional.one_hot(torch.randint(0, 5, (B, H, W), generator=g), 5).permute(0, 3, 1, 2).float()
+    return rain, dem, lu.contiguous()
+
+
+def model(gpu, seed):
+    from pl_convlstm_gan_amd import Generator
+    torch.manual_seed(seed)
+    m = Generator(hidden_dims=[16, 32], lu_channels=5, scale_factor=1).to(gpu)
+    return m
+
+
+def check_vs_oracle(gpu, m, rain, dem, lu, seed):
+    """Forward and all parameter gradients against the oracle (fp32 and bf16-storage emulation)."""
+    out = m(rain.to(gpu), dem.to(gpu), lu.to(gpu))
+    params = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    with torch.no_grad():
+        ref = O.generator_forward(params, rain, dem, lu, scale_factor=1)
+    leaf = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    emu = O.generator_forward(leaf, rain, dem, lu, scale_factor=1, emulate="bf16")
+    scale = float(ref.abs().max())
+    assert out.shape == ref.shape
+    assert relmax(out.detach().cpu(), ref) <= 2e-2
+    assert float((out.detach().cpu() - emu.detach()).abs().max()) <= 4e-3 * scale
+    wgt = torch.rand(out.shape, generator=torch.Generator().manual_seed(seed)) + 0.5
+    (out * wgt.to(gpu)).sum().backward()
+    (emu * wgt).sum().backward()
+    for k, p in m.named_parameters():
+        emax, el2 = relmax(p.grad.cpu(), leaf[k].grad), rel_l2(p.grad.cpu(), leaf[k].grad)
+        assert emax <= 3e-2 and el2 <= 3e-2, (k, emax, el2)
+        p.grad = None
+
+
+def check_properties(gpu, m, rain, dem, lu, t_cut):
+    """Bit-exact, size-independent properties of a rollout: repeatability, independence of the batch
+    elements, causality (frames before t_cut ignore later inputs); then repeatability of the gradients."""
+    rain, dem, lu = rain.to(gpu), dem.to(gpu), lu.to(gpu)
+    B = rain.shape[0]
+    with torch.no_grad():
+        a = m(rain, dem, lu).clone()
+        assert torch.equal(a, m(rain, dem, lu))
+        for i in sorted({0, B - 1}):
+            single = m(rain[i:i + 1].contiguous(), dem[i:i + 1].contiguous(), lu[i:i + 1].contiguous())
+            assert torch.equal(single[0], a[i])
+        rain2 = rain.clone()
+        rain2[:, t_cut:] += 1.0
+        c = m(rain2, dem, lu)
+        assert torch.equal(c[:, :t_cut], a[:, :t_cut])
+        assert not torch.equal(c[:, t_cut:], a[:, t_cut:])
+    assert torch.isfinite(a).all()
+    grads = []
+    for _ in range(2):
+        out = m(rain, dem, lu)
+        assert torch.equal(out.detach(), a)          # the training forward equals the inference forward
+        (out * out).sum().backward()
+        grads.append({k: p.grad.clone() for k, p in m.named_parameters()})
+        for p in m.parameters():
+            p.grad = None
+    for k in grads[0]:
+        assert torch.isfinite(grads[0][k]).all(), k
+        assert torch.equal(grads[0][k], grads[1][k]), k
+
+
+def test_c2_vs_oracle(gpu):
+    m = model(gpu, 21)
+    check_vs_oracle(gpu, m, *synthetic(2, 10, 128, 128, 22), seed=23)
+
+
+def test_c2_full_batch_properties(gpu):
+    m = model(gpu, 21)
+    check_properties(gpu, m, *synthetic(8, 10, 128, 128, 24), t_cut=6)
+
+
+def test_c4_long_horizon_vs_oracle(gpu):
+    m = model(gpu, 31)
+    check_vs_oracle(gpu, m, *synthetic(1, 20, 256, 256, 32), seed=33)
+
+
+def test_c4_full_size_properties(gpu):
+    m = model(gpu, 31)
+    check_properties(gpu, m, *synthetic(4, 20, 256, 256, 34), t_cut=13)
+
+
+def test_c5_shape_vs_oracle(gpu):
+    m = model(gpu, 41)
+    check_vs_oracle(gpu, m, *synthetic(1, 2, 512, 512, 42), seed=43)
+
+
+def test_c5_shape_full_horizon_properties(gpu):
+    m = model(gpu, 41)
+    check_properties(gpu, m, *synthetic(1, 10, 512, 512, 44), t_cut=6)

@@ -61,7 +61,9 @@ def test_geometry_and_lazy_blocks():
     assert (n, fh, fw) == (3, 256, 256) and m.target_size == (256, 256)
 
 
+@pytest.mark.skipif(torch.cuda.is_available(), reason="with a GPU, CPU operands are staged onto it instead")
 def test_no_cpu_fallback():
+    """Without a GPU nothing computes: CPU operands are only ever staged onto the GPU."""
     from pl_convlstm_gan_amd import ConvLSTMCell, Generator
     m = Generator(hidden_dims=[16, 32], lu_channels=5, scale_factor=1)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
@@ -100,3 +102,18 @@ def test_grad_bucket_carries_an_extra_element():
         assert p.grad.shape == p.shape and torch.equal(p.grad, w * 0.5)
     assert float(bucket.extra()) == 0.5
     assert GradBucket(params).gather().numel() == 11  # without an extra element nothing is appended
+
+
+def test_bench_refuses_a_rank_count_it_cannot_honour():
+    """`python bench.py --gpus N` with N above the box's GPU count, or inside a torchrun environment
+    whose WORLD_SIZE disagrees with --gpus, exits non-zero before running anything (it must never print
+    a line that says n_gpus: 1 for a --gpus 8 request)."""
+    import subprocess
+    import sys
+    bench = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, bench, "--gpus", "64"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "n_gpus" not in r.stdout and "nothing was run" in r.stderr
+    env["WORLD_SIZE"] = "1"
+    r = subprocess.run([sys.executable, bench, "--gpus", "2"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "n_gpus" not in r.stdout and "WORLD_SIZE=1" in r.stderr
