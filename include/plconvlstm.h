@@ -7,8 +7,10 @@
  * Conventions
  *   - every function returns 0 on success, a negative PLC_E* code on failure; the message of
  *     the last failure on the calling thread is available from plc_last_error();
- *   - the caller owns every buffer (workspaces included); the library allocates nothing, keeps
- *     no device state, and is re-entrant;
+ *   - the caller owns every buffer (workspaces included); the library allocates nothing and is
+ *     re-entrant; the only device state it keeps is the fixed staging array of
+ *     plc_convlstm_cell_fwd_noalloc (see there), the only host state a per-device cache of immutable
+ *     facts (CU count, "LDS limit raised" flags, that array's address);
  *   - every call is asynchronous on the hipStream_t passed as `stream` (a `void*` here so the
  *     header needs no HIP include); nothing synchronises;
  *   - tensors crossing the boundary are fp32, NCHW-contiguous, 16-byte aligned, exactly as the
@@ -86,6 +88,30 @@ int plc_convlstm_cell_fwd(const float* x, const float* h, const float* c,
                           float* h_next, float* c_next,
                           void* workspace, size_t workspace_bytes,
                           int B, int Cin, int Ch, int H, int W, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * ConvLSTM cell forward without any allocation.  This entry point has no counterpart in the
+ * reference: it exists for callers that cannot allocate device memory -- code under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc -- and therefore cannot bring the
+ * workspace plc_convlstm_cell_fwd asks for.  Same arithmetic and same kernels as
+ * plc_convlstm_cell_fwd (identical results, bit for bit); the staging buffers (layout conversions,
+ * packed weights, CB8 outputs) live in a fixed array inside the library's device image:
+ *   - size limit: the call needs plc_convlstm_cell_workspace_bytes(B, Cin, Ch, H, W) bytes of it and
+ *     fails with PLC_EWORKSPACE beyond PLC_STATIC_SCRATCH_BYTES (32 MiB: e.g. (Cin, Ch) = (16, 32)
+ *     up to 80 000 pixels per call, B = 1 at 256x256); nothing runs in that case;
+ *   - every GPU the library is used on holds its own copy of the array until the process ends;
+ *   - calls on one GPU share that GPU's array: calls that overlap in time on one device (two streams,
+ *     two threads) race; issue them on one stream or serialise them;
+ *   - the call makes no hipMalloc / hipFree and no allocating library call; its first use on a device
+ *     looks the array's address up once (hipGetSymbolAddress), so make one call per device before
+ *     starting a graph capture.
+ * ------------------------------------------------------------------------------------- */
+#define PLC_STATIC_SCRATCH_BYTES (32u << 20)
+size_t plc_convlstm_cell_noalloc_max_bytes(void);
+int plc_convlstm_cell_fwd_noalloc(const float* x, const float* h, const float* c,
+                                  const float* weight, const float* bias,
+                                  float* h_next, float* c_next,
+                                  int B, int Cin, int Ch, int H, int W, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Generator rollout, forward.  Replaces Generator.forward (src/models/generator.py:94-205):

@@ -16,6 +16,7 @@ EXPORTS = (
     "plc_nchw_f32_to_cb8_bf16", "plc_cb8_bf16_to_nchw_f32", "plc_nchw_f32_to_cb8_f32", "plc_cb8_f32_to_nchw_f32",
     "plc_packed_weight_bytes", "plc_packed_bias_bytes", "plc_pack_conv_weight",
     "plc_convlstm_cell_fwd_cb8", "plc_convlstm_cell_workspace_bytes", "plc_convlstm_cell_fwd",
+    "plc_convlstm_cell_noalloc_max_bytes", "plc_convlstm_cell_fwd_noalloc",
     "plc_generator_workspace_bytes", "plc_generator_rollout_fwd", "plc_generator_workspace_offset",
     "plc_convlstm_cell_bwd_workspace_bytes", "plc_convlstm_cell_bwd", "plc_lstm_pointwise_bwd",
     "plc_generator_bwd_workspace_bytes", "plc_generator_rollout_bwd",
@@ -111,6 +112,10 @@ def lib():
     L.plc_convlstm_cell_workspace_bytes.argtypes = [i, i, i, i, i]
     L.plc_convlstm_cell_fwd.restype = i
     L.plc_convlstm_cell_fwd.argtypes = [p, p, p, p, p, p, p, p, sz, i, i, i, i, i, p]
+    L.plc_convlstm_cell_noalloc_max_bytes.restype = sz
+    L.plc_convlstm_cell_noalloc_max_bytes.argtypes = []
+    L.plc_convlstm_cell_fwd_noalloc.restype = i
+    L.plc_convlstm_cell_fwd_noalloc.argtypes = [p, p, p, p, p, p, p, i, i, i, i, i, p]
     L.plc_generator_workspace_bytes.restype = sz
     L.plc_generator_workspace_bytes.argtypes = [C.POINTER(RolloutDesc)]
     L.plc_generator_rollout_fwd.restype = i

@@ -1,5 +1,6 @@
 // C ABI of libplconvlstm (see include/plconvlstm.h): argument checking, workspace carving and
-// kernel launches.  No allocation, no synchronisation, no global device state.
+// kernel launches.  No allocation, no synchronisation; the only device state is the fixed staging
+// array of plc_convlstm_cell_fwd_noalloc.
 #include <hip/hip_runtime.h>
 #include <stdarg.h>
 #include <stdio.h>
@@ -362,6 +363,53 @@ extern "C" int plc_convlstm_cell_fwd(const float* x, const float* h, const float
     if ((rc = plc_cb8_bf16_to_nchw_f32(ws + s.ho, h_next, B, Ch, H, W, stream))) return rc;
     if ((rc = plc_cb8_f32_to_nchw_f32((float*)(ws + s.co), c_next, B, Ch, H, W, stream))) return rc;
     return PLC_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// ConvLSTM cell forward for callers that cannot allocate: the staging area is a fixed array in the
+// library's own device image instead of a caller workspace.
+// ---------------------------------------------------------------------------------------------
+// One copy of this array exists on every GPU the library runs on, for the life of the process.  In
+// host code the NAME of a __device__ array is only a handle for the runtime, not a device address:
+// its address on the current device comes from hipGetSymbolAddress, is looked up once per device and
+// is what every launch below receives.
+static __device__ __align__(256) unsigned char plc_static_scratch[PLC_STATIC_SCRATCH_BYTES];
+static void* g_static_scratch_ptr[64] = {nullptr};   // per device, written once
+
+static int static_scratch_ptr(void** out) {
+    const int dev = current_device();
+    if (dev < 0) return plc_fail(PLC_EHIP, "plc_convlstm_cell_fwd_noalloc: no current device (or device index >= 64)");
+    if (!g_static_scratch_ptr[dev]) {
+        void* p = nullptr;
+        PLC_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(plc_static_scratch)));
+        if (!p) return plc_fail(PLC_EHIP, "plc_convlstm_cell_fwd_noalloc: the scratch array has no address on device %d", dev);
+        g_static_scratch_ptr[dev] = p;
+    }
+    *out = g_static_scratch_ptr[dev];
+    return PLC_OK;
+}
+
+extern "C" size_t plc_convlstm_cell_noalloc_max_bytes(void) { return (size_t)PLC_STATIC_SCRATCH_BYTES; }
+
+extern "C" int plc_convlstm_cell_fwd_noalloc(const float* x, const float* h, const float* c, const float* weight,
+                                             const float* bias, float* h_next, float* c_next, int B, int Cin,
+                                             int Ch, int H, int W, void* stream) {
+    PLC_REQUIRE(x && h && c && weight && h_next && c_next, "plc_convlstm_cell_fwd_noalloc: null pointer");
+    PLC_REQUIRE(B > 0 && Cin > 0 && Ch > 0 && H > 0 && W > 0, "plc_convlstm_cell_fwd_noalloc: non-positive size");
+    const size_t need = cell_ws(B, Cin, Ch, H, W).total;
+    if (need > (size_t)PLC_STATIC_SCRATCH_BYTES)
+        return plc_fail(PLC_EWORKSPACE,
+                        "plc_convlstm_cell_fwd_noalloc: B=%d, Cin=%d, Ch=%d, %dx%d needs %zu bytes of staging, the "
+                        "built-in area holds %zu; use plc_convlstm_cell_fwd with a caller workspace",
+                        B, Cin, Ch, H, W, need, (size_t)PLC_STATIC_SCRATCH_BYTES);
+    void* scratch = nullptr;
+    int rc = static_scratch_ptr(&scratch);
+    if (rc) return rc;
+    // Every byte of the staging area that a kernel reads is written earlier in this same call
+    // (layout conversions, weight packing, the cell's outputs), so nothing has to start at zero and
+    // the previous call's contents are simply overwritten.
+    return plc_convlstm_cell_fwd(x, h, c, weight, bias, h_next, c_next, scratch, (size_t)PLC_STATIC_SCRATCH_BYTES,
+                                 B, Cin, Ch, H, W, stream);
 }
 
 // ---------------------------------------------------------------------------------------------
