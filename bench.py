@@ -185,6 +185,8 @@ def main():
     ap.add_argument("--global-batch", type=int, default=0,
                     help="total batch over all ranks (strong-scaling anchor, e.g. 32 for BASELINE configs[2]); "
                          "default: the config's per-GPU batch on every rank (weak scaling)")
+    ap.add_argument("--hidden", default="16,32", help="hidden_dims of the generator (the benchmark configs use 16,32; "
+                    "32,64 is the reference's class default and runs on the run-time-width kernels)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
     if args.gpus < 1:
@@ -237,7 +239,8 @@ def main():
             raise SystemExit(f"bench.py: --global-batch {args.global_batch} does not divide over {world} ranks")
         B, scaling = args.global_batch // world, "strong"
     torch.manual_seed(0)                       # identical initial weights on every rank
-    model = Generator(hidden_dims=[16, 32], lu_channels=5, scale_factor=s)
+    hidden = [int(v) for v in args.hidden.split(",")]
+    model = Generator(hidden_dims=hidden, lu_channels=5, scale_factor=s)
     rain, dem, lu, coords, values = synthetic(B, T, H, W, s, 1234 + rank, device)
     model = model.to(device)
     with torch.no_grad():
@@ -298,7 +301,7 @@ def main():
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"{args.config}: {what}, B={B}/GPU, T={T}, {H}x{W} -> {H * s}x{W * s}, 1 channel, "
-                                   f"hidden [16,32], L=5, scale_factor={s}, {N_STATIONS} stations",
+                                   f"hidden [{args.hidden}], L=5, scale_factor={s}, {N_STATIONS} stations",
                        "global_batch": world * B, "T": T, "mode": args.mode,
                        "parallelism": f"dp{world} (batch sharded; one flat-gradient all-reduce per step)"},
             "fwd_frames_per_s": world * B * T * n_fwd / dt_fwd,
@@ -306,7 +309,7 @@ def main():
         # whole-path view next to the per-kernel rooflines: algorithmic forward FLOPs per frame
         # (171 104 per output pixel at scale 1; a train step is 3x: data + weight gradients) and, for the
         # forward, the algorithmic bf16 tensor traffic per frame (402 elements per pixel) over the step time
-        if s == 1:
+        if s == 1 and hidden == [16, 32]:
             px = H * W
             fwd_flop = FLOP_PER_PX_FWD * px * world * B * T
             res["step_mfma_frac"] = (3 if args.mode == "train" else 1) * fwd_flop / (dt / args.steps) / (world * PEAK_BF16)

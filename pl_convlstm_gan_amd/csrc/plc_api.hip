@@ -8,6 +8,7 @@
 
 #include "../../include/plconvlstm.h"
 #include "plc_conv_kernel.h"
+#include "plc_convg_kernel.h"
 #include "plc_misc_kernels.h"
 
 // ---------------------------------------------------------------------------------------------
@@ -90,13 +91,20 @@ extern "C" int plc_cb8_f32_to_nchw_f32(const float* src, float* dst, int N, int 
 // weight packing
 // ---------------------------------------------------------------------------------------------
 static inline int pack_ncb(int c0, int c1) { return cdiv(c0, 8) + cdiv(c1, 8); }
+// Widths with weight-stationary kernel instantiations (plc_conv_kernel.h); every other width that is a
+// multiple of 8 takes the run-time-width kernel (plc_convg_kernel.h).
+static inline bool cell_fast(int Cin, int Ch) { return Cin == 16 && (Ch == 16 || Ch == 32); }
+static inline bool widths_fast(int C1, int C2) { return C1 == 16 && C2 == 32; }
 static inline int pack_nks(int c0, int c1, int ks) { return (ks * ks * pack_ncb(c0, c1) + 1) / 2; }
 // number of 32-row M tiles; LSTM and PixelShuffle convs regroup rows but keep the count
 static inline int pack_nmt(int cout) { return cdiv(cout, 32); }
 
+// (the chunk-major order of the run-time-width kernel pads every chunk to whole k-steps, so it never
+// has fewer k-steps than the plain order: buffers are sized for it and serve both)
 extern "C" size_t plc_packed_weight_bytes(int cout, int c0, int c1, int ks) {
     if (cout <= 0 || c0 <= 0 || c1 < 0 || ks <= 0) return 0;
-    return align256((size_t)pack_nmt(cout) * pack_nks(c0, c1, ks) * 64 * 16);
+    const int nks = plc_g_nks(pack_ncb(c0, c1), ks);
+    return align256((size_t)pack_nmt(cout) * (nks > pack_nks(c0, c1, ks) ? nks : pack_nks(c0, c1, ks)) * 64 * 16);
 }
 extern "C" size_t plc_packed_bias_bytes(int cout) {
     if (cout <= 0) return 0;
@@ -109,13 +117,16 @@ static int pack_blocks(long long elems) {
 }
 
 // Forward packing job (rows = output channels regrouped per `mode`).
+// generic != 0: chunk-major K order for the run-time-width kernel.
 static PackJob pack_job(const float* w, const float* bias, void* wpk, float* bpk, int cout, int c0, int c1, int ks,
-                        int mode) {
+                        int mode, int generic = 0) {
     PackJob jb;
     memset(&jb, 0, sizeof(jb));
     jb.w = w; jb.bias = bias; jb.wpk = (unsigned short*)wpk; jb.bpk = bpk;
     jb.cout = cout; jb.c0 = c0; jb.c1 = c1; jb.ks = ks; jb.mode = mode;
-    jb.n_mt = pack_nmt(cout); jb.nks_w = pack_nks(c0, c1, ks);
+    jb.n_mt = pack_nmt(cout);
+    jb.nks_w = generic ? plc_g_nks(pack_ncb(c0, c1), ks) : pack_nks(c0, c1, ks);
+    jb.chunk = generic ? PLC_G_CHUNK : 0;
     jb.ch_per_gate = cout / 4; jb.transposed = 0; jb.ksplit = 1;
     jb.n_blocks = pack_blocks((long long)jb.n_mt * jb.nks_w * 512);
     return jb;
@@ -155,7 +166,9 @@ extern "C" int plc_pack_conv_weight(const float* w, const float* bias, void* wpk
     PLC_REQUIRE(mode >= 0 && mode <= 2, "plc_pack_conv_weight: bad mode %d", mode);
     if (mode != PLC_PACK_PLAIN) PLC_REQUIRE(cout % 32 == 0, "plc_pack_conv_weight: cout %d must be a multiple of 32 for mode %d", cout, mode);
     PLC_REQUIRE(aligned16(wpk) && aligned16(bpk), "plc_pack_conv_weight: packed buffers must be 16-byte aligned");
-    const PackJob jb = pack_job(w, bias, wpk, bpk, cout, c0, c1, ks, mode);
+    // a ConvLSTM gate conv of a width without a weight-stationary instantiation runs on the
+    // run-time-width kernel, which wants its own K order (plc_convlstm_cell_fwd_cb8 makes the same choice)
+    const PackJob jb = pack_job(w, bias, wpk, bpk, cout, c0, c1, ks, mode, mode == PLC_PACK_LSTM && !cell_fast(c0, c1));
     hipLaunchKernelGGL(plc_pack_weight_kernel, dim3(jb.n_blocks), dim3(256), 0, (hipStream_t)stream, jb);
     PLC_HIP(hipGetLastError());
     return PLC_OK;
@@ -166,21 +179,26 @@ extern "C" int plc_pack_conv_weight(const float* w, const float* bias, void* wpk
 static inline int packT_nmt(int c0, int c1) { return cdiv(8 * pack_ncb(c0, c1), 32); }
 static inline int packT_nks(int cout, int ks, int ksplit) { return (ks * ks * (cdiv(cout, 8) / ksplit) + 1) / 2; }
 static size_t packedT_weight_bytes(int cout, int c0, int c1, int ks, int ksplit) {
-    return align256((size_t)packT_nmt(c0, c1) * ksplit * packT_nks(cout, ks, ksplit) * 64 * 16);
+    const size_t plain = (size_t)ksplit * packT_nks(cout, ks, ksplit), chunked = (size_t)plc_g_nks(cdiv(cout, 8), ks);
+    return align256((size_t)packT_nmt(c0, c1) * (plain > chunked ? plain : chunked) * 64 * 16);
 }
-static PackJob pack_job_T(const float* w, void* wpk, float* bpk, int cout, int c0, int c1, int ks, int ksplit) {
+static PackJob pack_job_T(const float* w, void* wpk, float* bpk, int cout, int c0, int c1, int ks, int ksplit,
+                          int generic = 0) {
     PackJob jb;
     memset(&jb, 0, sizeof(jb));
     jb.w = w; jb.wpk = (unsigned short*)wpk; jb.bpk = bpk;
     jb.cout = cout; jb.c0 = c0; jb.c1 = c1; jb.ks = ks;
-    jb.n_mt = packT_nmt(c0, c1); jb.nks_w = packT_nks(cout, ks, ksplit);
+    if (generic) ksplit = 1;
+    jb.n_mt = packT_nmt(c0, c1);
+    jb.nks_w = generic ? plc_g_nks(cdiv(cout, 8), ks) : packT_nks(cout, ks, ksplit);
+    jb.chunk = generic ? PLC_G_CHUNK : 0;
     jb.transposed = 1; jb.ksplit = ksplit;
     jb.n_blocks = pack_blocks((long long)jb.n_mt * ksplit * jb.nks_w * 512);
     return jb;
 }
 static int pack_conv_weight_T(const float* w, void* wpk, float* bpk, int cout, int c0, int c1, int ks, int ksplit,
-                              hipStream_t st) {
-    const PackJob jb = pack_job_T(w, wpk, bpk, cout, c0, c1, ks, ksplit);
+                              hipStream_t st, int generic = 0) {
+    const PackJob jb = pack_job_T(w, wpk, bpk, cout, c0, c1, ks, ksplit, generic);
     hipLaunchKernelGGL(plc_pack_weight_kernel, dim3(jb.n_blocks), dim3(256), 0, st, jb);
     PLC_HIP(hipGetLastError());
     return PLC_OK;
@@ -261,6 +279,25 @@ static int launch_conv(ConvArgs a, int n_img, int n_mgroups, hipStream_t st) {
     return launch_conv_th<NCB0, NCB1, NMT, KS, STAGE, EPI, 8>(a, n_img, n_mgroups, st);
 }
 
+// The run-time-width kernel: ncb0 / ncb1 input channel blocks from src0 / src1, n_mt 32-row output tiles.
+template <int KS, int STAGE, int EPI>
+static int launch_convg(ConvArgs a, int ncb0, int ncb1, int n_mt, int n_img, hipStream_t st) {
+    if (ncb0 <= 0 || ncb1 < 0 || n_mt <= 0) return plc_fail(PLC_EINVAL, "conv: bad channel counts");
+    a.g_ncb0 = ncb0;
+    a.g_ncb1 = ncb1;
+    a.g_nmt = n_mt;
+    a.tiles_x = cdiv(a.W, 32);
+    a.tiles_y = cdiv(a.H, PLC_G_TH);
+    const long long tiles = (long long)n_img * a.tiles_x * a.tiles_y;
+    if (tiles <= 0 || tiles >= (1ll << 31)) return plc_fail(PLC_EINVAL, "conv: bad tile count %lld", tiles);
+    a.n_tiles = (int)tiles;
+    a.n_blocks = a.n_tiles;
+    hipLaunchKernelGGL((plc_convg_kernel<KS, STAGE, EPI>), dim3(a.n_tiles, cdiv(n_mt, 4)), dim3(256),
+                       plc_convg_lds_bytes<KS>(), st, a);
+    PLC_HIP(hipGetLastError());
+    return PLC_OK;
+}
+
 static ConvArgs conv_args(int H, int W, int n_in) {
     ConvArgs a;
     memset(&a, 0, sizeof(a));
@@ -289,18 +326,25 @@ static ConvArgs cell_conv_args(const void* x, const void* h, const float* c_in, 
     return a;
 }
 
-static int cell_fwd_cb8(const void* x, const void* h, const float* c_in, const void* wpk, const float* bpk,
-                        void* h_out, float* c_out, void* gates, int B, int Cin, int Ch, int H, int W,
-                        hipStream_t st) {
-    const ConvArgs a = cell_conv_args(x, h, c_in, wpk, bpk, h_out, c_out, gates, B, Cin, Ch, H, W);
+// One ConvLSTM cell launch; a.save_gates selects the variant that stores i,f,o,g for the backward pass.
+static int launch_cell(const ConvArgs& a, int B, int Cin, int Ch, hipStream_t st) {
+    const bool gates = a.save_gates != 0;
     if (Cin == 16 && Ch == 16)
         return gates ? launch_conv<2, 2, 2, 3, STAGE_CB8, EPI_LSTM_SAVE>(a, B, 1, st)
                      : launch_conv<2, 2, 2, 3, STAGE_CB8, EPI_LSTM>(a, B, 1, st);
     if (Cin == 16 && Ch == 32)
         return gates ? launch_conv<2, 4, 4, 3, STAGE_CB8, EPI_LSTM_SAVE>(a, B, 1, st)
                      : launch_conv<2, 4, 4, 3, STAGE_CB8, EPI_LSTM>(a, B, 1, st);
-    return plc_fail(PLC_EUNSUPPORTED,
-                    "ConvLSTM cell (Cin=%d, Ch=%d) is outside the compiled kernel set {(16,16), (16,32)}", Cin, Ch);
+    if (Cin % 8 == 0 && Ch % 8 == 0)
+        return gates ? launch_convg<3, STAGE_CB8, EPI_LSTM_SAVE>(a, Cin / 8, Ch / 8, Ch / 8, B, st)
+                     : launch_convg<3, STAGE_CB8, EPI_LSTM>(a, Cin / 8, Ch / 8, Ch / 8, B, st);
+    return plc_fail(PLC_EUNSUPPORTED, "ConvLSTM cell (Cin=%d, Ch=%d): channel counts must be multiples of 8", Cin, Ch);
+}
+
+static int cell_fwd_cb8(const void* x, const void* h, const float* c_in, const void* wpk, const float* bpk,
+                        void* h_out, float* c_out, void* gates, int B, int Cin, int Ch, int H, int W,
+                        hipStream_t st) {
+    return launch_cell(cell_conv_args(x, h, c_in, wpk, bpk, h_out, c_out, gates, B, Cin, Ch, H, W), B, Cin, Ch, st);
 }
 
 extern "C" int plc_convlstm_cell_fwd_cb8(const void* x, const void* h, const float* c_in, const void* wpk,
@@ -343,9 +387,8 @@ extern "C" int plc_convlstm_cell_fwd(const float* x, const float* h, const float
     PLC_REQUIRE(x && h && c && weight && h_next && c_next && workspace, "plc_convlstm_cell_fwd: null pointer");
     PLC_REQUIRE(B > 0 && Cin > 0 && Ch > 0 && H > 0 && W > 0, "plc_convlstm_cell_fwd: non-positive size");
     PLC_REQUIRE(((uintptr_t)workspace & 255) == 0, "plc_convlstm_cell_fwd: workspace must be 256-byte aligned");
-    if (!((Cin == 16 && Ch == 16) || (Cin == 16 && Ch == 32)))
-        return plc_fail(PLC_EUNSUPPORTED,
-                        "ConvLSTM cell (Cin=%d, Ch=%d) is outside the compiled kernel set {(16,16), (16,32)}", Cin, Ch);
+    if (Cin % 8 != 0 || Ch % 8 != 0)
+        return plc_fail(PLC_EUNSUPPORTED, "ConvLSTM cell (Cin=%d, Ch=%d): channel counts must be multiples of 8", Cin, Ch);
     const CellWs s = cell_ws(B, Cin, Ch, H, W);
     if (workspace_bytes < s.total)
         return plc_fail(PLC_EWORKSPACE, "plc_convlstm_cell_fwd: workspace %zu < %zu bytes", workspace_bytes, s.total);
@@ -437,8 +480,8 @@ static int rollout_plan(const plc_rollout_desc* d, RolloutPlan* p) {
     PLC_REQUIRE(d->B > 0 && d->T > 0 && d->H > 0 && d->W > 0, "rollout: non-positive B/T/H/W");
     PLC_REQUIRE(d->L > 0 && d->L <= 16, "rollout: lu_channels=%d unsupported (1..16)", d->L);
     PLC_REQUIRE(d->n_blocks >= 0 && d->n_blocks <= 8, "rollout: n_blocks=%d out of range", d->n_blocks);
-    if (!(d->C1 == 16 && d->C2 == 32))
-        return plc_fail(PLC_EUNSUPPORTED, "rollout: hidden_dims=[%d,%d] is outside the compiled kernel set {[16,32]}",
+    if (d->C1 <= 0 || d->C2 <= 0 || d->C1 % 8 != 0 || d->C2 % 8 != 0 || d->C1 > 512 || d->C2 > 512)
+        return plc_fail(PLC_EUNSUPPORTED, "rollout: hidden_dims=[%d,%d]: both must be multiples of 8 (at most 512)",
                         d->C1, d->C2);
     PLC_REQUIRE(d->dem_H > 0 && d->dem_W > 0 && d->lu_H > 0 && d->lu_W > 0, "rollout: bad aux size");
     const int C1 = d->C1, C2 = d->C2, B = d->B, T = d->T;
@@ -550,20 +593,25 @@ extern "C" int plc_generator_rollout_fwd(const plc_rollout_desc* d, void* stream
     // ---- parameters -> MFMA fragment order ----------------------------------------------
     PackBatch batch;
     pack_batch_begin(&batch);
-    auto pack = [&](const float* w, const float* b, const Packed& q, int cout, int c0, int c1, int ks, int mode) {
-        return pack_batch_add(&batch, pack_job(w, b, ws + q.w, (float*)(ws + q.b), cout, c0, c1, ks, mode), st);
+    // [16,32] has weight-stationary instantiations for every conv; other widths send the convs whose
+    // shape depends on the widths through the run-time-width kernel (gen = its K order).  The stem, the
+    // aux 3x3 convs and the last conv have fixed input widths and use the instantiated kernels always.
+    const bool fast = widths_fast(C1, C2);
+    const int gen = fast ? 0 : 1;
+    auto pack = [&](const float* w, const float* b, const Packed& q, int cout, int c0, int c1, int ks, int mode, int g) {
+        return pack_batch_add(&batch, pack_job(w, b, ws + q.w, (float*)(ws + q.b), cout, c0, c1, ks, mode, g), st);
     };
-    if ((rc = pack(d->init_w, d->init_b, p.init, C1, 3, 0, 3, PLC_PACK_PLAIN))) return rc;
-    if ((rc = pack(d->cell1_w, d->cell1_b, p.cell1, 4 * C1, C1, C1, 3, PLC_PACK_LSTM))) return rc;
-    if ((rc = pack(d->cell2_w, d->cell2_b, p.cell2, 4 * C2, C1, C2, 3, PLC_PACK_LSTM))) return rc;
-    if ((rc = pack(d->dem0_w, d->dem0_b, p.dem0, C2 / 2, 1, 0, 3, PLC_PACK_PLAIN))) return rc;
-    if ((rc = pack(d->dem2_w, d->dem2_b, p.dem2, C2, C2 / 2, 0, 1, PLC_PACK_PLAIN))) return rc;
-    if ((rc = pack(d->lu0_w, d->lu0_b, p.lu0, C2 / 2, L, 0, 3, PLC_PACK_PLAIN))) return rc;
-    if ((rc = pack(d->lu2_w, d->lu2_b, p.lu2, C2, C2 / 2, 0, 1, PLC_PACK_PLAIN))) return rc;
+    if ((rc = pack(d->init_w, d->init_b, p.init, C1, 3, 0, 3, PLC_PACK_PLAIN, 0))) return rc;
+    if ((rc = pack(d->cell1_w, d->cell1_b, p.cell1, 4 * C1, C1, C1, 3, PLC_PACK_LSTM, !cell_fast(C1, C1)))) return rc;
+    if ((rc = pack(d->cell2_w, d->cell2_b, p.cell2, 4 * C2, C1, C2, 3, PLC_PACK_LSTM, !cell_fast(C1, C2)))) return rc;
+    if ((rc = pack(d->dem0_w, d->dem0_b, p.dem0, C2 / 2, 1, 0, 3, PLC_PACK_PLAIN, 0))) return rc;
+    if ((rc = pack(d->dem2_w, d->dem2_b, p.dem2, C2, C2 / 2, 0, 1, PLC_PACK_PLAIN, gen))) return rc;
+    if ((rc = pack(d->lu0_w, d->lu0_b, p.lu0, C2 / 2, L, 0, 3, PLC_PACK_PLAIN, 0))) return rc;
+    if ((rc = pack(d->lu2_w, d->lu2_b, p.lu2, C2, C2 / 2, 0, 1, PLC_PACK_PLAIN, gen))) return rc;
     for (int k = 0; k < d->n_blocks; ++k)
-        if ((rc = pack(d->up_w[k], d->up_b[k], p.up[k], 4 * C2, C2, 0, 3, PLC_PACK_PIXSHUF))) return rc;
-    if ((rc = pack(d->post0_w, d->post0_b, p.post0, 32, C2, 0, 3, PLC_PACK_PLAIN))) return rc;
-    if ((rc = pack(d->post2_w, d->post2_b, p.post2, 1, 32, 0, 3, PLC_PACK_PLAIN))) return rc;
+        if ((rc = pack(d->up_w[k], d->up_b[k], p.up[k], 4 * C2, C2, 0, 3, PLC_PACK_PIXSHUF, gen))) return rc;
+    if ((rc = pack(d->post0_w, d->post0_b, p.post0, 32, C2, 0, 3, PLC_PACK_PLAIN, gen))) return rc;
+    if ((rc = pack(d->post2_w, d->post2_b, p.post2, 1, 32, 0, 3, PLC_PACK_PLAIN, 0))) return rc;
     if ((rc = pack_batch_flush(&batch, st))) return rc;
 
     // ---- t-invariant gates: sigmoid(conv1x1(relu(conv3x3(aux)))) for DEM and land use, multiplied
@@ -584,7 +632,8 @@ extern "C" int plc_generator_rollout_fwd(const plc_rollout_desc* d, void* stream
         a.bpk = (const float*)(ws + p.dem0.b);
         a.act = ACT_RELU;
         a.ncb_out = mcb;
-        if ((rc = launch_conv<1, 0, 1, 3, STAGE_CB8, EPI_ACT_CB8>(a, B, 1, st))) return rc;
+        const int mid_groups = cdiv(mcb, 4);          // 32-row output groups of the aux 3x3 convs
+        if ((rc = launch_conv<1, 0, 1, 3, STAGE_CB8, EPI_ACT_CB8>(a, B, mid_groups, st))) return rc;
 
         a = conv_args(oH, oW, B);
         a.src0 = tens(ws + p.dem_mid, mcb * ohw * 16, 0);
@@ -593,7 +642,9 @@ extern "C" int plc_generator_rollout_fwd(const plc_rollout_desc* d, void* stream
         a.bpk = (const float*)(ws + p.dem2.b);
         a.act = ACT_SIGMOID;
         a.ncb_out = C2 / 8;
-        if ((rc = launch_conv<2, 0, 1, 1, STAGE_CB8, EPI_ACT_CB8>(a, B, 1, st))) return rc;
+        if ((rc = fast ? launch_conv<2, 0, 1, 1, STAGE_CB8, EPI_ACT_CB8>(a, B, 1, st)
+                       : launch_convg<1, STAGE_CB8, EPI_ACT_CB8>(a, mcb, 0, cdiv(C2, 32), B, st)))
+            return rc;
 
         a = conv_args(oH, oW, B);
         a.src0 = tens(ws + p.lu_hr, cdiv(L, 8) * ohw * 16, 0);
@@ -602,8 +653,8 @@ extern "C" int plc_generator_rollout_fwd(const plc_rollout_desc* d, void* stream
         a.bpk = (const float*)(ws + p.lu0.b);
         a.act = ACT_RELU;
         a.ncb_out = mcb;
-        if (L <= 8) rc = launch_conv<1, 0, 1, 3, STAGE_CB8, EPI_ACT_CB8>(a, B, 1, st);
-        else rc = launch_conv<2, 0, 1, 3, STAGE_CB8, EPI_ACT_CB8>(a, B, 1, st);
+        if (L <= 8) rc = launch_conv<1, 0, 1, 3, STAGE_CB8, EPI_ACT_CB8>(a, B, mid_groups, st);
+        else rc = launch_conv<2, 0, 1, 3, STAGE_CB8, EPI_ACT_CB8>(a, B, mid_groups, st);
         if (rc) return rc;
 
         a = conv_args(oH, oW, B);
@@ -615,7 +666,9 @@ extern "C" int plc_generator_rollout_fwd(const plc_rollout_desc* d, void* stream
         a.bpk = (const float*)(ws + p.lu2.b);
         a.act = ACT_SIGMOID;
         a.ncb_out = C2 / 8;
-        if ((rc = launch_conv<2, 0, 1, 1, STAGE_CB8, EPI_ACT_CB8>(a, B, 1, st))) return rc;
+        if ((rc = fast ? launch_conv<2, 0, 1, 1, STAGE_CB8, EPI_ACT_CB8>(a, B, 1, st)
+                       : launch_convg<1, STAGE_CB8, EPI_ACT_CB8>(a, mcb, 0, cdiv(C2, 32), B, st)))
+            return rc;
     }
 
     // ---- stem over all T*B frames: x_t = relu(conv3x3([rain, row, col])) ------------------
@@ -629,7 +682,7 @@ extern "C" int plc_generator_rollout_fwd(const plc_rollout_desc* d, void* stream
         a.bpk = (const float*)(ws + p.init.b);
         a.act = ACT_RELU;
         a.ncb_out = C1 / 8;
-        if ((rc = launch_conv<1, 0, 1, 3, STAGE_COORD, EPI_ACT_CB8>(a, T * B, 1, st))) return rc;
+        if ((rc = launch_conv<1, 0, 1, 3, STAGE_COORD, EPI_ACT_CB8>(a, T * B, cdiv(C1, 32), st))) return rc;
     }
 
     // ---- recurrence -----------------------------------------------------------------------
@@ -659,12 +712,8 @@ extern "C" int plc_generator_rollout_fwd(const plc_rollout_desc* d, void* stream
         // (Running cell 1 of step t+1 in the same launch as cell 2 of step t was measured: the two
         // kinds of workgroup share each SIMD's matrix pipe and finish together, so nothing is gained.)
         for (int t = 0; t < T; ++t) {
-            if ((rc = save ? launch_conv<2, 2, 2, 3, STAGE_CB8, EPI_LSTM_SAVE>(cell1(t), B, 1, st)
-                           : launch_conv<2, 2, 2, 3, STAGE_CB8, EPI_LSTM>(cell1(t), B, 1, st)))
-                return rc;
-            if ((rc = save ? launch_conv<2, 4, 4, 3, STAGE_CB8, EPI_LSTM_SAVE>(cell2(t), B, 1, st)
-                           : launch_conv<2, 4, 4, 3, STAGE_CB8, EPI_LSTM>(cell2(t), B, 1, st)))
-                return rc;
+            if ((rc = launch_cell(cell1(t), B, C1, C1, st))) return rc;
+            if ((rc = launch_cell(cell2(t), B, C1, C2, st))) return rc;
         }
     }
 
@@ -678,7 +727,9 @@ extern "C" int plc_generator_rollout_fwd(const plc_rollout_desc* d, void* stream
         a.out0 = tens(ws + p.up_out[k], (long long)(C2 / 8) * fh * fw * 4 * 16, 0);
         a.wpk = (const uint4*)(ws + p.up[k].w);
         a.bpk = (const float*)(ws + p.up[k].b);
-        if ((rc = launch_conv<4, 0, 4, 3, STAGE_CB8, EPI_PIXSHUF_RELU>(a, NI, 1, st))) return rc;
+        if ((rc = fast ? launch_conv<4, 0, 4, 3, STAGE_CB8, EPI_PIXSHUF_RELU>(a, NI, 1, st)
+                       : launch_convg<3, STAGE_CB8, EPI_PIXSHUF_RELU>(a, C2 / 8, 0, C2 / 8, NI, st)))
+            return rc;
         feat = ws + p.up_out[k];
         fh *= 2;
         fw *= 2;
@@ -709,7 +760,9 @@ extern "C" int plc_generator_rollout_fwd(const plc_rollout_desc* d, void* stream
         a.bpk = (const float*)(ws + p.post0.b);
         a.act = ACT_RELU;
         a.ncb_out = 4;
-        if ((rc = launch_conv<4, 0, 1, 3, STAGE_CB8_GATED, EPI_ACT_CB8>(a, NI, 1, st))) return rc;
+        if ((rc = fast ? launch_conv<4, 0, 1, 3, STAGE_CB8_GATED, EPI_ACT_CB8>(a, NI, 1, st)
+                       : launch_convg<3, STAGE_CB8_GATED, EPI_ACT_CB8>(a, C2 / 8, 0, 1, NI, st)))
+            return rc;
 
         a = conv_args(oH, oW, B);
         a.src0 = tens(ws + p.p0, 4 * ohw * 16, (long long)B * 4 * ohw * 16);

@@ -59,7 +59,7 @@ static int arena_flush(SlabArena* ar, hipStream_t st) {
 template <int NCB0, int NCB1, int MT, int KS, int STAGE>
 static int launch_wgrad(ConvArgs in, PlcTensor dz, int mcb_valid, int n_img, SlabArena* ar,
                         float* dw, float* db, int cout, int c0, int c1, hipStream_t st,
-                        const PlcTensor* dz_mask = nullptr) {
+                        const PlcTensor* dz_mask = nullptr, int ci_off = 0, int c_total = 0) {
     using G = WgradGeom<NCB0 + NCB1, MT, KS>;
     if (dz_mask && STAGE == STAGE_CB8)
         return plc_fail(PLC_EUNSUPPORTED, "wgrad: the plain CB8 staging does not load a dz mask");
@@ -97,6 +97,7 @@ static int launch_wgrad(ConvArgs in, PlcTensor dz, int mcb_valid, int n_img, Sla
     jb.slab = slab; jb.dw = dw; jb.db = db;
     jb.n_slabs = grid; jb.rows_pad = MT * 32; jb.cols_pad = G::NT * 32;
     jb.cout = cout; jb.c0 = c0; jb.c1 = c1; jb.ks = KS; jb.ncb = NCB0 + NCB1;
+    jb.ci_off = ci_off; jb.c_total = c_total > 0 ? c_total : c0 + c1;
     const long long groups = ((long long)cout * G::NT * 32 + 31) / 32;      // 32 output elements per block pass
     jb.n_blocks = (int)(groups < 1 ? 1 : (groups > 1024 ? 1024 : groups));
     jb.first_block = ar->blocks;
@@ -138,10 +139,55 @@ static int launch_wgrad_cout1(PlcTensor x, PlcTensor dy, int n_in, int H, int W,
     jb.slab = slab; jb.dw = dw; jb.db = db;
     jb.n_slabs = grid; jb.rows_pad = 1; jb.cols_pad = W1_COLS;
     jb.cout = 1; jb.c0 = 32; jb.c1 = 0; jb.ks = 3; jb.ncb = 4;
+    jb.ci_off = 0; jb.c_total = 32;
     jb.n_blocks = W1_COLS / 32;
     jb.first_block = ar->blocks;
     ar->blocks += jb.n_blocks;
     ar->tb.job[ar->tb.n++] = jb;
+    return PLC_OK;
+}
+
+// Weight gradient of a conv of ANY width on an instantiated kernel <NCBK, 0, MT, KS, STAGE>: the dz rows
+// are taken 32*MT at a time and the input channel blocks of src0 and then src1 NCBK at a time; every
+// (row group, input chunk) pair is one launch on offset pointers whose slab the common reduction
+// scatters into its rectangle of dW (row offset by pointer, input-channel offset by ci_off).  dz is
+// re-read once per input chunk: the price of running widths that have no instantiation of their own.
+// in.zero_state != 0: src1 of the first n_in images is the unstored zero initial state.
+template <int NCBK, int MT, int KS, int STAGE>
+static int wgrad_chunked(const ConvArgs& in, int c0, int c1, PlcTensor dz, int cout, int n_img, SlabArena* ar,
+                         float* dw, float* db, hipStream_t st, const PlcTensor* dz_mask = nullptr) {
+    const long long plane = (long long)in.H * in.W * 16;
+    const int taps = KS * KS, ctot = c0 + c1, mcb = cdiv(cout, 8);
+    for (int mg = 0; mg * 4 * MT < mcb; ++mg) {
+        PlcTensor dzg = dz, maskg;
+        dzg.p += (long long)mg * 4 * MT * plane;
+        if (dz_mask) {
+            maskg = *dz_mask;
+            maskg.p += (long long)mg * 4 * MT * plane;
+        }
+        const int mcb_valid = mcb - mg * 4 * MT < 4 * MT ? mcb - mg * 4 * MT : 4 * MT;
+        const int rows = cout - mg * 32 * MT < 32 * MT ? cout - mg * 32 * MT : 32 * MT;
+        bool first = true;
+        for (int src = 0; src < 2; ++src) {
+            const int c_src = src == 0 ? c0 : c1, nb_src = cdiv(c_src, 8);
+            for (int cb = 0; cb < nb_src; cb += NCBK) {
+                ConvArgs ci = in;
+                ci.src0 = src == 0 ? in.src0 : in.src1;
+                if (STAGE != STAGE_COORD) ci.src0.p += (long long)cb * plane;
+                memset(&ci.src1, 0, sizeof(ci.src1));
+                if (STAGE == STAGE_CB8_GATED) ci.gate.p += (long long)cb * plane;
+                ci.zero_state = (src == 1 && in.zero_state) ? 2 : 0;
+                ci.g_ncb0 = nb_src - cb < NCBK ? nb_src - cb : NCBK;
+                const int ch_here = c_src - 8 * cb < 8 * NCBK ? c_src - 8 * cb : 8 * NCBK;
+                int rc = launch_wgrad<NCBK, 0, MT, KS, STAGE>(ci, dzg, mcb_valid, n_img, ar,
+                                                              dw + (long long)mg * 32 * MT * ctot * taps,
+                                                              (first && db) ? db + mg * 32 * MT : nullptr, rows, ch_here, 0,
+                                                              st, dz_mask ? &maskg : nullptr, (src == 0 ? 0 : c0) + 8 * cb, ctot);
+                if (rc) return rc;
+                first = false;
+            }
+        }
+    }
     return PLC_OK;
 }
 
@@ -181,7 +227,9 @@ static int cell_dgrad(const void* dz, const void* wpkT, const float* bpk0, void*
     a.ncb_out = (Cin + Ch) / 8;
     if (Cin == 16 && Ch == 16) return launch_conv_th<8, 0, 1, 3, STAGE_CB8, EPI_ACT_CB8, 8, 1>(a, B, 1, st);
     if (Cin == 16 && Ch == 32) return launch_conv_th<16, 0, 2, 3, STAGE_CB8, EPI_ACT_CB8, 4, 2>(a, B, 1, st);
-    return plc_fail(PLC_EUNSUPPORTED, "ConvLSTM cell backward (Cin=%d, Ch=%d) is outside the compiled kernel set", Cin, Ch);
+    if (Cin % 8 == 0 && Ch % 8 == 0)
+        return launch_convg<3, STAGE_CB8, EPI_ACT_CB8>(a, 4 * Ch / 8, 0, cdiv(Cin + Ch, 32), B, st);
+    return plc_fail(PLC_EUNSUPPORTED, "ConvLSTM cell backward (Cin=%d, Ch=%d): channel counts must be multiples of 8", Cin, Ch);
 }
 static int cell_dgrad_ksplit(int Cin, int Ch) { return (Cin == 16 && Ch == 32) ? 2 : 1; }
 
@@ -199,11 +247,14 @@ static int cell_wgrad(const void* dz, PlcTensor x, PlcTensor h, int n_in, int n_
         return launch_wgrad<2, 2, 2, 3, STAGE_CB8>(in, dzt, 8, n_img, slab, dw, db, 64, 16, 16, st);
     if (Cin == 16 && Ch == 32)
         return launch_wgrad<2, 4, 4, 3, STAGE_CB8>(in, dzt, 16, n_img, slab, dw, db, 128, 16, 32, st);
-    return plc_fail(PLC_EUNSUPPORTED, "ConvLSTM cell backward (Cin=%d, Ch=%d) is outside the compiled kernel set", Cin, Ch);
+    if (Cin % 8 == 0 && Ch % 8 == 0)
+        return wgrad_chunked<4, 4, 3, STAGE_CB8>(in, Cin, Ch, dzt, 4 * Ch, n_img, slab, dw, db, st);
+    return plc_fail(PLC_EUNSUPPORTED, "ConvLSTM cell backward (Cin=%d, Ch=%d): channel counts must be multiples of 8", Cin, Ch);
 }
 static size_t cell_wgrad_slab_bytes(int Cin, int Ch) {
     if (Cin == 16 && Ch == 16) return wgrad_slab_bytes<2, 2, 2, 3>();
-    return wgrad_slab_bytes<2, 4, 4, 3>();
+    if (Cin == 16 && Ch == 32) return wgrad_slab_bytes<2, 4, 4, 3>();
+    return wgrad_slab_bytes<4, 0, 4, 3>();
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -255,9 +306,8 @@ extern "C" int plc_convlstm_cell_bwd(const float* x, const float* h, const float
                 "plc_convlstm_cell_bwd: null pointer");
     PLC_REQUIRE(B > 0 && H > 0 && W > 0, "plc_convlstm_cell_bwd: non-positive size");
     PLC_REQUIRE(((uintptr_t)workspace & 255) == 0, "plc_convlstm_cell_bwd: workspace must be 256-byte aligned");
-    if (!((Cin == 16 && Ch == 16) || (Cin == 16 && Ch == 32)))
-        return plc_fail(PLC_EUNSUPPORTED,
-                        "ConvLSTM cell (Cin=%d, Ch=%d) is outside the compiled kernel set {(16,16), (16,32)}", Cin, Ch);
+    if (Cin <= 0 || Ch <= 0 || Cin % 8 != 0 || Ch % 8 != 0)
+        return plc_fail(PLC_EUNSUPPORTED, "ConvLSTM cell (Cin=%d, Ch=%d): channel counts must be multiples of 8", Cin, Ch);
     const CellBwdWs s = cell_bwd_ws(B, Cin, Ch, H, W);
     if (workspace_bytes < s.total)
         return plc_fail(PLC_EWORKSPACE, "plc_convlstm_cell_bwd: workspace %zu < %zu bytes", workspace_bytes, s.total);
@@ -285,7 +335,7 @@ extern "C" int plc_convlstm_cell_bwd(const float* x, const float* h, const float
         return rc;
     // data gradient
     if ((rc = pack_conv_weight_T(weight, ws + s.wpkT, (float*)(ws + s.bpk0), 4 * Ch, Cin, Ch, 3,
-                                 cell_dgrad_ksplit(Cin, Ch), st)))
+                                 cell_dgrad_ksplit(Cin, Ch), st, !cell_fast(Cin, Ch))))
         return rc;
     if ((rc = cell_dgrad(ws + s.dz, ws + s.wpkT, (const float*)(ws + s.bpk0), ws + s.dcat, B, Cin, Ch, H, W, st)))
         return rc;
@@ -324,6 +374,12 @@ struct BwdPlan {
 };
 
 static size_t max_sz(size_t a, size_t b) { return a > b ? a : b; }
+// zero bias rows for the data-gradient convs: 32 per output tile of the widest one, at least 8 tiles
+static size_t bwd_zero_bias_floats(int C1, int C2) {
+    const int widest = C1 + C2 > 2 * C1 ? C1 + C2 : 2 * C1;
+    const int tiles = cdiv(widest, 32) > 8 ? cdiv(widest, 32) : 8;
+    return (size_t)tiles * 32;
+}
 
 static int bwd_plan(const plc_rollout_desc* d, const RolloutPlan& fp, BwdPlan* p) {
     const int C1 = d->C1, C2 = d->C2, B = d->B, T = d->T, NI = d->B * d->T;
@@ -342,7 +398,7 @@ static int bwd_plan(const plc_rollout_desc* d, const RolloutPlan& fp, BwdPlan* p
     p->lu2T = take(packedT_weight_bytes(C2, C2 / 2, 0, 1, 1));
     p->dem2T = take(packedT_weight_bytes(C2, C2 / 2, 0, 1, 1));
     for (int k = 0; k < d->n_blocks; ++k) p->upT[k] = take(packedT_weight_bytes(4 * C2, C2, 0, 3, 2));
-    p->bpk0 = take(8 * 32 * sizeof(float));
+    p->bpk0 = take(bwd_zero_bias_floats(C1, C2) * sizeof(float));
     p->d_pre0 = take((size_t)NI * 4 * ohw * 16);
     p->d_feat = take((size_t)NI * (C2 / 8) * ohw * 16);
     p->d_pre = take((size_t)NI * (C2 / 8) * ohw * 16);
@@ -368,6 +424,9 @@ static int bwd_plan(const plc_rollout_desc* d, const RolloutPlan& fp, BwdPlan* p
     sb += 2 * wgrad_slab_bytes<2, 0, 1, 1>();                                                // the two 1x1 gate convs
     sb += wgrad_slab_bytes<1, 0, 1, 3>() + max_sz(wgrad_slab_bytes<1, 0, 1, 3>(), wgrad_slab_bytes<2, 0, 1, 3>());
     sb += (size_t)d->n_blocks * wgrad_slab_bytes<4, 0, 4, 3>();                              // upsample blocks
+    // widths without their own instantiations run the chunked launches: room for a few of their slabs
+    // (the arena reduces early whenever it runs full)
+    if (!widths_fast(C1, C2)) sb += 4 * max_sz(wgrad_slab_bytes<4, 0, 4, 3>(), wgrad_slab_bytes<4, 0, 4, 1>());
     p->slab_bytes = sb;
     p->slab = take(sb);
     p->total = o;
@@ -417,22 +476,24 @@ extern "C" int plc_generator_rollout_bwd(const plc_rollout_desc* d, const plc_ro
     const int mcb = cdiv(C2 / 2, 8);
     const long long fimg = (C2 / 8) * ohw * 16;   // one C2-channel image at output resolution
 
-    PLC_HIP(hipMemsetAsync(wb + bp.bpk0, 0, 8 * 32 * sizeof(float), st));
+    PLC_HIP(hipMemsetAsync(wb + bp.bpk0, 0, bwd_zero_bias_floats(C1, C2) * sizeof(float), st));
+    const bool fast = widths_fast(C1, C2);
+    const int gen = fast ? 0 : 1;
     // ---- transposed (data-gradient) weights -------------------------------------------------
     {
         PackBatch batch;
         pack_batch_begin(&batch);
-        auto packT = [&](const float* w, size_t at, int cout, int c0, int c1, int ks, int ksplit) {
-            return pack_batch_add(&batch, pack_job_T(w, wb + at, nullptr, cout, c0, c1, ks, ksplit), st);
+        auto packT = [&](const float* w, size_t at, int cout, int c0, int c1, int ks, int ksplit, int g) {
+            return pack_batch_add(&batch, pack_job_T(w, wb + at, nullptr, cout, c0, c1, ks, ksplit, g), st);
         };
-        if ((rc = packT(d->post2_w, bp.post2T, 1, 32, 0, 3, 1))) return rc;
-        if ((rc = packT(d->post0_w, bp.post0T, 32, C2, 0, 3, 1))) return rc;
-        if ((rc = packT(d->cell1_w, bp.cell1T, 4 * C1, C1, C1, 3, 1))) return rc;
-        if ((rc = packT(d->cell2_w, bp.cell2T, 4 * C2, C1, C2, 3, 2))) return rc;
-        if ((rc = packT(d->lu2_w, bp.lu2T, C2, C2 / 2, 0, 1, 1))) return rc;
-        if ((rc = packT(d->dem2_w, bp.dem2T, C2, C2 / 2, 0, 1, 1))) return rc;
+        if ((rc = packT(d->post2_w, bp.post2T, 1, 32, 0, 3, 1, 0))) return rc;
+        if ((rc = packT(d->post0_w, bp.post0T, 32, C2, 0, 3, 1, 0))) return rc;
+        if ((rc = packT(d->cell1_w, bp.cell1T, 4 * C1, C1, C1, 3, cell_dgrad_ksplit(C1, C1), !cell_fast(C1, C1)))) return rc;
+        if ((rc = packT(d->cell2_w, bp.cell2T, 4 * C2, C1, C2, 3, cell_dgrad_ksplit(C1, C2), !cell_fast(C1, C2)))) return rc;
+        if ((rc = packT(d->lu2_w, bp.lu2T, C2, C2 / 2, 0, 1, 1, gen))) return rc;
+        if ((rc = packT(d->dem2_w, bp.dem2T, C2, C2 / 2, 0, 1, 1, gen))) return rc;
         for (int k = 0; k < d->n_blocks; ++k)
-            if ((rc = packT(d->up_w[k], bp.upT[k], 4 * C2, C2, 0, 3, 2))) return rc;
+            if ((rc = packT(d->up_w[k], bp.upT[k], 4 * C2, C2, 0, 3, 2, gen))) return rc;
         if ((rc = pack_batch_flush(&batch, st))) return rc;
     }
 
@@ -458,8 +519,10 @@ extern "C" int plc_generator_rollout_bwd(const plc_rollout_desc* d, const plc_ro
         in = conv_args(oH, oW, B);
         in.src0 = tens(wf + fp.fin, fimg, (long long)B * fimg);
         in.gate = tens(wf + fp.gate, fimg, 0);
-        if ((rc = launch_wgrad<4, 0, 1, 3, STAGE_CB8_GATED>(in, tens(wb + bp.d_pre0, 4 * ohw * 16, (long long)B * 4 * ohw * 16),
-                                                            4, NI, slab, g->post0_w, g->post0_b, 32, C2, 0, st)))
+        if ((rc = fast ? launch_wgrad<4, 0, 1, 3, STAGE_CB8_GATED>(in, tens(wb + bp.d_pre0, 4 * ohw * 16, (long long)B * 4 * ohw * 16),
+                                                                   4, NI, slab, g->post0_w, g->post0_b, 32, C2, 0, st)
+                       : wgrad_chunked<4, 1, 3, STAGE_CB8_GATED>(in, C2, 0, tens(wb + bp.d_pre0, 4 * ohw * 16, (long long)B * 4 * ohw * 16),
+                                                                 32, NI, slab, g->post0_w, g->post0_b, st)))
             return rc;
         a = conv_args(oH, oW, B);
         a.src0 = tens(wb + bp.d_pre0, 4 * ohw * 16, (long long)B * 4 * ohw * 16);
@@ -467,7 +530,7 @@ extern "C" int plc_generator_rollout_bwd(const plc_rollout_desc* d, const plc_ro
         a.wpk = (const uint4*)(wb + bp.post0T);
         a.bpk = bpk0;
         a.ncb_out = C2 / 8;
-        if ((rc = launch_conv<4, 0, 1, 3, STAGE_CB8, EPI_ACT_CB8>(a, NI, 1, st))) return rc;
+        if ((rc = launch_conv<4, 0, 1, 3, STAGE_CB8, EPI_ACT_CB8>(a, NI, cdiv(C2, 32), st))) return rc;
     }
     // With no upsample block and no resize between the gates and the recurrence (scale 1), the gradient
     // of the gated feature map IS cell 2's incoming dh: its pointwise backward then forms
@@ -503,8 +566,10 @@ extern "C" int plc_generator_rollout_bwd(const plc_rollout_desc* d, const plc_ro
             // 1x1 conv (C2/2 -> C2): weight gradient, then data gradient masked by the ReLU of the 3x3 conv
             ConvArgs in = conv_args(oH, oW, B);
             in.src0 = tens(wf + q.mid, mcb * ohw * 16, 0);
-            if ((rc = launch_wgrad<2, 0, 1, 1, STAGE_CB8>(in, tens(wb + q.d_pre, fimg, 0), C2 / 8, B, slab,
-                                                          q.g2w, q.g2b, C2, C2 / 2, 0, st)))
+            if ((rc = fast ? launch_wgrad<2, 0, 1, 1, STAGE_CB8>(in, tens(wb + q.d_pre, fimg, 0), C2 / 8, B, slab,
+                                                                 q.g2w, q.g2b, C2, C2 / 2, 0, st)
+                           : wgrad_chunked<4, 4, 1, STAGE_CB8>(in, C2 / 2, 0, tens(wb + q.d_pre, fimg, 0), C2, B, slab,
+                                                               q.g2w, q.g2b, st)))
                 return rc;
             ConvArgs a = conv_args(oH, oW, B);
             a.src0 = tens(wb + q.d_pre, fimg, 0);
@@ -514,16 +579,19 @@ extern "C" int plc_generator_rollout_bwd(const plc_rollout_desc* d, const plc_ro
             a.wpk = (const uint4*)(wb + q.w2T);
             a.bpk = bpk0;
             a.ncb_out = mcb;
-            if ((rc = launch_conv<4, 0, 1, 1, STAGE_CB8, EPI_ACT_CB8>(a, B, 1, st))) return rc;
+            if ((rc = fast ? launch_conv<4, 0, 1, 1, STAGE_CB8, EPI_ACT_CB8>(a, B, 1, st)
+                           : launch_convg<1, STAGE_CB8, EPI_ACT_CB8>(a, C2 / 8, 0, cdiv(C2 / 2, 32), B, st)))
+                return rc;
             // 3x3 conv (aux -> C2/2): weight gradient only (the aux maps need no gradient)
             in = conv_args(oH, oW, B);
             in.src0 = tens(wf + q.hr, cdiv(q.cin, 8) * ohw * 16, 0);
+            // (more than 32 mid channels: one launch per 32-row group of dz)
             if (q.cin <= 8)
-                rc = launch_wgrad<1, 0, 1, 3, STAGE_CB8>(in, tens(wb + q.d_mid, mcb * ohw * 16, 0), mcb, B, slab,
-                                                         q.g0w, q.g0b, C2 / 2, q.cin, 0, st);
+                rc = wgrad_chunked<1, 1, 3, STAGE_CB8>(in, q.cin, 0, tens(wb + q.d_mid, mcb * ohw * 16, 0), C2 / 2, B, slab,
+                                                       q.g0w, q.g0b, st);
             else
-                rc = launch_wgrad<2, 0, 1, 3, STAGE_CB8>(in, tens(wb + q.d_mid, mcb * ohw * 16, 0), mcb, B, slab,
-                                                         q.g0w, q.g0b, C2 / 2, q.cin, 0, st);
+                rc = wgrad_chunked<2, 1, 3, STAGE_CB8>(in, q.cin, 0, tens(wb + q.d_mid, mcb * ohw * 16, 0), C2 / 2, B, slab,
+                                                       q.g0w, q.g0b, st);
             if (rc) return rc;
         }
     }
@@ -555,8 +623,10 @@ extern "C" int plc_generator_rollout_bwd(const plc_rollout_desc* d, const plc_ro
         PLC_HIP(hipGetLastError());
         ConvArgs in = conv_args(kh, kw, NI);
         in.src0 = tens(in_k, (C2 / 8) * khw * 16, 0);
-        if ((rc = launch_wgrad<4, 0, 4, 3, STAGE_CB8>(in, tens(wb + bp.d_conv[k], (4 * C2 / 8) * khw * 16, 0), 4 * C2 / 8,
-                                                      NI, slab, g->up_w[k], g->up_b[k], 4 * C2, C2, 0, st)))
+        if ((rc = fast ? launch_wgrad<4, 0, 4, 3, STAGE_CB8>(in, tens(wb + bp.d_conv[k], (4 * C2 / 8) * khw * 16, 0), 4 * C2 / 8,
+                                                             NI, slab, g->up_w[k], g->up_b[k], 4 * C2, C2, 0, st)
+                       : wgrad_chunked<4, 4, 3, STAGE_CB8>(in, C2, 0, tens(wb + bp.d_conv[k], (4 * C2 / 8) * khw * 16, 0), 4 * C2,
+                                                           NI, slab, g->up_w[k], g->up_b[k], st)))
             return rc;
         ConvArgs a = conv_args(kh, kw, NI);
         a.src0 = tens(wb + bp.d_conv[k], (4 * C2 / 8) * khw * 16, 0);
@@ -564,7 +634,9 @@ extern "C" int plc_generator_rollout_bwd(const plc_rollout_desc* d, const plc_ro
         a.wpk = (const uint4*)(wb + bp.upT[k]);
         a.bpk = bpk0;
         a.ncb_out = C2 / 8;
-        if ((rc = launch_conv_th<16, 0, 1, 3, STAGE_CB8, EPI_ACT_CB8, 4, 2>(a, NI, 1, st))) return rc;
+        if ((rc = fast ? launch_conv_th<16, 0, 1, 3, STAGE_CB8, EPI_ACT_CB8, 4, 2>(a, NI, 1, st)
+                       : launch_convg<3, STAGE_CB8, EPI_ACT_CB8>(a, 4 * C2 / 8, 0, cdiv(C2, 32), NI, st)))
+            return rc;
         cur = wb + bp.d_in[k];
     }
     // ---- backpropagation through time ---------------------------------------------------------
@@ -608,8 +680,8 @@ extern "C" int plc_generator_rollout_bwd(const plc_rollout_desc* d, const plc_ro
         in.row_tab = d->row_tab;
         in.col_tab = d->col_tab;
         const PlcTensor relu_of = tens(wf + fp.xs, fp.img1, (long long)B * fp.img1);      // stem output
-        if ((rc = launch_wgrad<1, 0, 1, 3, STAGE_COORD>(in, tens(wb + bp.dcat1, cat1, (long long)B * cat1), C1 / 8, NI,
-                                                        slab, g->init_w, g->init_b, C1, 3, 0, st, &relu_of)))
+        if ((rc = wgrad_chunked<1, 1, 3, STAGE_COORD>(in, 3, 0, tens(wb + bp.dcat1, cat1, (long long)B * cat1), C1, NI,
+                                                      slab, g->init_w, g->init_b, st, &relu_of)))
             return rc;
     }
     // ---- gate-conv weight gradients, batched over all T*B frames -------------------------------

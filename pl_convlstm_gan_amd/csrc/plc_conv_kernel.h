@@ -69,6 +69,8 @@ struct ConvArgs {
     int save_gates;      // EPI_LSTM: also store i,f,o,g (bf16) for the backward pass
     int zero_state;      // EPI_LSTM: the recurrent inputs (src1 = h, c_in) are all zero and are not read
     int mul_mode;        // EPI_ACT_CB8 with `mul`: MUL_PRODUCT (v *= m) or MUL_RELU_MASK (v = m > 0 ? v : 0)
+    int g_ncb0, g_ncb1;  // run-time-width kernel (plc_convg_kernel.h) only: channel blocks of src0 / src1
+    int g_nmt;           // ... and the conv's 32-row output tiles
     PlcTensor src0;      // CB8 bf16, first NCB0 channel blocks   (STAGE_COORD / STAGE_F32_1CH: fp32 plane)
     PlcTensor src1;      // CB8 bf16, next NCB1 channel blocks
     PlcTensor gate;      // STAGE_CB8_GATED: CB8 bf16 multiplier of src0

@@ -29,6 +29,9 @@ __device__ __forceinline__ int plc_padded_to_concat(int cb, int j, int c0, int c
 // transposed != 0 (data gradient): rows = channels of the block-padded concat [src0 | src1]
 //      (plain order), K channels = the cout output channels, taps flipped:
 //      W'[ci][o][dy][dx] = w[o][ci][ks-1-dy][ks-1-dx].
+// chunk > 0 (the run-time-width conv kernel, ksplit 1): the K units are ordered chunk-major -- the
+//      channel blocks are taken `chunk` at a time and inside a chunk of nb blocks unit u = tap * nb +
+//      (block inside the chunk); a chunk with an odd unit count ends in a zero unit.
 // One conv's packing job; `block` of `n_blocks` (256 threads each) share it grid-stride fashion.
 struct PackJob {
     const float* w;
@@ -36,6 +39,7 @@ struct PackJob {
     unsigned short* wpk;
     float* bpk;
     int cout, c0, c1, ks, mode, n_mt, nks_w, ch_per_gate, transposed, ksplit;
+    int chunk;
     int first_block, n_blocks;      // position inside a multi-job launch
 };
 
@@ -60,8 +64,20 @@ __device__ __forceinline__ void plc_pack_weight_body(const PackJob& jb, int bloc
         const int q = rest % ksplit;
         const int mt = rest / ksplit;
         const int r = lane & 31, half = lane >> 5;
-        const int u = 2 * s + half;
-        const int tap = u / ncbw, cb = q * ncbw + u % ncbw;
+        int tap, cb;
+        if (jb.chunk > 0) {
+            // every chunk but the last is full, so the k-step's chunk is a plain quotient
+            const int nks_full = (taps * jb.chunk + 1) / 2;
+            const int c = s / nks_full;
+            const int nb = ncb_k - c * jb.chunk < jb.chunk ? ncb_k - c * jb.chunk : jb.chunk;
+            const int u = 2 * (s - c * nks_full) + half;
+            tap = u / nb;
+            cb = c * jb.chunk + u % nb;
+        } else {
+            const int u = 2 * s + half;
+            tap = u / ncbw;
+            cb = q * ncbw + u % ncbw;
+        }
         float v = 0.0f;
         if (tap < taps) {
             const int dy = tap / ks, dx = tap % ks;

@@ -26,7 +26,11 @@ typedef __attribute__((__vector_size__(4 * sizeof(short)))) short s16x4_t;
 #define PLC_AS3 __attribute__((address_space(3)))
 
 struct WgradArgs {
-    ConvArgs in;       // H, W, tiles_x, tiles_y, n_in and the staging fields (src0, src1, gate, tabs)
+    ConvArgs in;       // H, W, tiles_x, tiles_y, n_in and the staging fields (src0, src1, gate, tabs);
+                       // in.g_ncb0 > 0: only that many of the input channel blocks exist (the rest read as
+                       // zero: the last chunk of a conv contracted in chunks of NCB blocks);
+                       // in.zero_state: 1 = src1 of the first n_in images is the unstored zero state,
+                       // 2 = src0 of the first n_in images is
     PlcTensor dz;      // CB8 bf16, ceil(cout/8) channel blocks
     PlcTensor dz_mask; // optional (p may be null): CB8 bf16 like dz; dz counts only where mask > 0 (ReLU backward)
     int mcb_valid;     // channel blocks present in dz
@@ -175,7 +179,7 @@ __global__ __launch_bounds__(512, 2) void plc_wgrad_kernel(const WgradArgs a) {
                 const int r = u - cb * G::PLANE;
                 const int ly = r / G::LW, lx = r - ly * G::LW;
                 const int gy = y0 - G::PAD + ly, gx = x0 - G::PAD + lx;
-                const bool ok = (gy >= 0) & (gy < H) & (gx >= 0) & (gx < W);
+                const bool ok = (gy >= 0) & (gy < H) & (gx >= 0) & (gx < W) & (a.in.g_ncb0 == 0 || cb < a.in.g_ncb0);
                 const long long pix = (long long)gy * W + gx;
                 if (STAGE == STAGE_COORD) {
                     pr = ok ? s0 + pix * 4 : z16;
@@ -184,7 +188,7 @@ __global__ __launch_bounds__(512, 2) void plc_wgrad_kernel(const WgradArgs a) {
                 } else {
                     const char* base = (NCB1 == 0 || cb < NCB0) ? s0 + cb * plane_b : s1 + (cb - NCB0) * plane_b;
                     // zero_state: src1 of the first n_in images is the (unstored) zero initial state
-                    const bool skip = NCB1 > 0 && cb >= NCB0 && a.in.zero_state != 0 && n < a.in.n_in;
+                    const bool skip = ((NCB1 > 0 && cb >= NCB0 && a.in.zero_state != 0) || a.in.zero_state == 2) && n < a.in.n_in;
                     p1 = (ok & !skip) ? base + pix * 16 : z16;
                     if (STAGE == STAGE_CB8_GATED) p2 = ok ? gt + cb * plane_b + pix * 16 : z16;
                 }
@@ -333,6 +337,7 @@ struct FinalizeJob {
     float* dw;
     float* db;
     int n_slabs, rows_pad, cols_pad, cout, c0, c1, ks, ncb;
+    int ci_off, c_total;            // the job's input channels are channels ci_off.. of a conv with c_total of them
     int first_block, n_blocks;      // position inside a multi-job launch
 };
 
@@ -377,7 +382,7 @@ __device__ __forceinline__ void plc_wgrad_finalize_body(const FinalizeJob& jb, i
                 const int tap = grp / ncbp;
                 const int cb = 2 * (grp % ncbp) + (c16 >> 3);
                 const int ci = cb < ncb ? plc_padded_to_concat(cb, c16 & 7, c0, c1) : -1;
-                if (ci >= 0) dw[((long long)o * (c0 + c1) + ci) * taps + tap] = t;
+                if (ci >= 0) dw[((long long)o * jb.c_total + jb.ci_off + ci) * taps + tap] = t;
             } else if (grp == taps * ncbp && c16 == 0) {
                 if (db) db[o] = t;
             }

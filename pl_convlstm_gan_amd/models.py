@@ -245,7 +245,7 @@ class Generator(nn.Module):
         L = _lib.lib()
         nbytes = L.plc_generator_workspace_bytes(C.byref(d))
         if nbytes == 0:
-            _lib.check(-2 if "compiled kernel set" in L.plc_last_error().decode() else -1, "Generator.forward")
+            _lib.check(-2 if "hidden_dims" in L.plc_last_error().decode() else -1, "Generator.forward")
         if fresh:
             # training: the workspace holds the activations saved for backward and is owned by
             # the autograd node, so a second forward cannot overwrite it

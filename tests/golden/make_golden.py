@@ -17,6 +17,9 @@ Files
   loss_*.npz          CombinedLoss components                             (combined_loss.py:23-191)
   step_s2.npz         one optimisation step in trainer.py:290-315 order, Adam built before the
                       first forward as trainer.py:153-158 does (lazy blocks are not updated)
+  genw_*.npz          Generator of other widths (the class default hidden_dims=[32,64] of
+                      generator.py:33, and [8,24]) with its own parameters ("param.<key>"), forward
+                      and parameter gradients
 """
 import os
 import sys
@@ -229,4 +232,41 @@ def step_case():
 
 
 step_case()
+
+
+# ------------------------------------------------------------------ other layer widths (own parameters)
+def wide_case(name, hidden, B, T, H, W, seed, ctor, with_grads):
+    torch.manual_seed(seed)
+    g = torch.Generator().manual_seed(seed + 1000)
+    m = Generator(lu_channels=5, **ctor) if hidden is None else Generator(hidden_dims=hidden, lu_channels=5, **ctor)
+    rain = rain_like(g, B, T, 1, H, W)
+    with torch.no_grad():
+        probe = m(rain[:1, :1], torch.zeros(1, 1, H, W), torch.zeros(1, 5, H, W))     # creates the lazy blocks
+    Hh, Wh = probe.shape[-2:]
+    dem = torch.rand(B, 1, Hh, Wh, generator=g)
+    lu = torch.nn.functional.one_hot(torch.randint(0, 5, (B, Hh, Wh), generator=g), 5).permute(0, 3, 1, 2).float().contiguous()
+    out = m(rain, dem, lu)
+    arrays = dict(rain=rain, dem=dem, lu=lu, out=out, n_blocks=np.int64(len(m.upsample_blocks)),
+                  hidden=np.asarray(m.hidden_dims, dtype=np.int64))
+    for k, v in m.state_dict().items():
+        arrays["param." + k] = v
+    N = 7
+    s_coords = torch.randint(0, min(H, W), (N, 2), generator=g).unsqueeze(0).repeat(B, 1, 1)
+    s_values = 20.0 * torch.rand(B, T, N, generator=g)
+    total, _ = CombinedLoss()(out, rain, s_coords, s_values, out.shape[-2] / H)
+    total.backward()
+    arrays.update(s_coords=s_coords, s_values=s_values, loss=total.detach())
+    for k, prm in m.named_parameters():
+        if with_grads == "all" or any(k.startswith(pfx) for pfx in with_grads):
+            arrays["grad." + k] = prm.grad
+    save(name, **arrays)
+
+
+# the reference's class default widths (generator.py:33: hidden_dims=[32, 64]), one upsample block;
+# gradients of the small tensors only (the file would otherwise double)
+wide_case("genw_default_s2.npz", None, 1, 2, 8, 8, 51, dict(scale_factor=2),
+          with_grads=("init_conv", "cell1.conv.bias", "cell2.conv.bias", "post_process.2", "post_process.0.bias",
+                      "dem_attn.conv.0", "lu_attn.conv.0", "lu_attn.conv.2.bias", "upsample_blocks.0.conv.bias"))
+# widths that are no multiple of 16: three hidden channel blocks, odd chunk sizes
+wide_case("genw_8_24_s1.npz", [8, 24], 2, 3, 12, 9, 52, dict(scale_factor=1), with_grads="all")
 print("done")

@@ -208,10 +208,10 @@ def test_reference_test_model_calls_as_written():
 
 def test_errors(gpu):
     from pl_convlstm_gan_amd import Generator
-    big = Generator(hidden_dims=[32, 64], lu_channels=5, scale_factor=1).to(gpu)
-    with pytest.raises(NotImplementedError):
+    odd = Generator(hidden_dims=[12, 20], lu_channels=5, scale_factor=1).to(gpu)     # widths must be multiples of 8
+    with pytest.raises(NotImplementedError, match="multiples of 8"):
         with torch.no_grad():
-            big(torch.zeros(1, 1, 1, 8, 8, device=gpu), torch.zeros(1, 1, 8, 8, device=gpu),
+            odd(torch.zeros(1, 1, 1, 8, 8, device=gpu), torch.zeros(1, 1, 8, 8, device=gpu),
                 torch.zeros(1, 5, 8, 8, device=gpu))
     # reference quirk: neither scale_factor nor target_grid_size -> AttributeError in forward
     q = Generator(hidden_dims=[16, 32], lu_channels=5).to(gpu)

@@ -140,3 +140,30 @@ def test_train_step_order():
         # entries whose gradient is ~0 are ill-conditioned under Adam's sign-like first step
         mask = gk.abs() > 1e-7
         assert float((expect - after)[mask].abs().max()) <= 2e-5, key
+
+
+WIDE_CASES = {"genw_default_s2.npz": ([32, 64], 2), "genw_8_24_s1.npz": ([8, 24], 1)}
+
+
+def wide_params(g):
+    return {k[6:]: v for k, v in g.items() if k.startswith("param.")}
+
+
+@pytest.mark.parametrize("name", sorted(WIDE_CASES))
+def test_other_layer_widths(name):
+    """Generators of other widths (the reference's class default [32,64]; [8,24]) with their own
+    parameters: forward, loss and parameter gradients of the oracle against the reference's."""
+    hidden, s = WIDE_CASES[name]
+    g = load_golden(name)
+    assert list(g["hidden"]) == hidden
+    p = wide_params(g)
+    out = O.generator_forward(p, g["rain"], g["dem"], g["lu"], scale_factor=s)
+    assert float((out - g["out"]).abs().max()) <= ATOL
+    loss, grads, _ = O.grads_of(p, g["rain"], g["dem"], g["lu"], g["s_coords"], g["s_values"], fwd_kw=dict(scale_factor=s))
+    assert abs(float(loss) - float(g["loss"])) <= 1e-5 * max(1.0, abs(float(g["loss"])))
+    checked = 0
+    for k, v in g.items():
+        if k.startswith("grad."):
+            assert float((grads[k[5:]] - v).abs().max()) <= 1e-4 * max(1e-3, float(v.abs().max())), k
+            checked += 1
+    assert checked >= 9
