@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "../../include/plconvlstm.h"
@@ -326,6 +327,12 @@ static ConvArgs cell_conv_args(const void* x, const void* h, const float* c_in, 
     return a;
 }
 
+// PLC_NO_PERSISTENT=1 in the environment keeps the recurrence on per-step launches (A/B timing, tests).
+static bool plc_no_persistent() {
+    const char* e = getenv("PLC_NO_PERSISTENT");
+    return e && e[0] && e[0] != '0';
+}
+
 // One ConvLSTM cell launch; a.save_gates selects the variant that stores i,f,o,g for the backward pass.
 static int launch_cell(const ConvArgs& a, int B, int Cin, int Ch, hipStream_t st) {
     const bool gates = a.save_gates != 0;
@@ -339,6 +346,107 @@ static int launch_cell(const ConvArgs& a, int B, int Cin, int Ch, hipStream_t st
         return gates ? launch_convg<3, STAGE_CB8, EPI_LSTM_SAVE>(a, Cin / 8, Ch / 8, Ch / 8, B, st)
                      : launch_convg<3, STAGE_CB8, EPI_LSTM>(a, Cin / 8, Ch / 8, Ch / 8, B, st);
     return plc_fail(PLC_EUNSUPPORTED, "ConvLSTM cell (Cin=%d, Ch=%d): channel counts must be multiples of 8", Cin, Ch);
+}
+
+// ---------------------------------------------------------------------------------------------
+// The recurrence of a whole rollout in ONE launch (small grids, where a cell launch is mostly fixed
+// cost: dispatch, argument and weight fetch, pipeline fill and drain).
+// ---------------------------------------------------------------------------------------------
+// Every workgroup owns one tile of one of the two cells for the whole rollout.  Phase p runs cell 1 of
+// step p next to cell 2 of step p - 1 (cell 2 of a step needs h1 of the same step, cell 1 of the next
+// step only h1 / c1 of this one), so T steps take T + 1 phases instead of 2 T dependent launches.
+// Between phases all workgroups meet at a counter in global memory: the arriving thread releases its
+// workgroup's stores at agent scope (they leave this XCD's L2), the leaving thread acquires (stale
+// lines are dropped), so the halo of the next phase's tile sees its neighbours' h.  Every workgroup
+// passes every barrier exactly once whether or not it has work in the phase, and the host launches the
+// kernel only when the whole grid is resident at once, so the wait always ends.
+// The cells' tensors are described once, with the byte stride of one time step as the outer stride of
+// every PlcTensor: image index t * B + b then addresses step t, and since tiles are numbered
+// image-major a workgroup reaches step t of its own tile by adding t * (tiles of one step) to its
+// tile number.  The descriptors stay in the kernel arguments untouched (copies adjusted per phase
+// cost more scalar registers than the cell kernels have to spare).
+struct PersistArgs {
+    ConvArgs c1z, c1, c2z, c2;  // cell 1 / cell 2; the z variants are step 0 (zero initial state: h, c not read)
+    int T, n1, n2;              // steps; tiles (= workgroups) of one step of cell 1 / cell 2
+    unsigned* counter;          // zero at launch
+};
+
+__device__ __forceinline__ void plc_grid_barrier(unsigned* counter, unsigned target) {
+    __syncthreads();                               // this workgroup's stores have been issued and counted
+    if (threadIdx.x == 0) {
+        __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        while (__hip_atomic_load(counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target)
+            __builtin_amdgcn_s_sleep(2);
+    }
+    __syncthreads();
+}
+
+template <int TH, bool SAVE>
+__global__ __launch_bounds__(256, (TH == 8 ? 1 : 2)) void plc_lstm_persistent_kernel(const PersistArgs p) {
+    extern __shared__ __attribute__((aligned(16))) uint4 plc_persist_tile[];
+    constexpr int EPI = SAVE ? EPI_LSTM_SAVE : EPI_LSTM;
+    if ((int)blockIdx.x < p.n1) {
+#pragma unroll 1
+        for (int phase = 0; phase <= p.T; ++phase) {
+            if (phase < p.T)
+                plc_conv_body<2, 2, 2, 3, STAGE_CB8, EPI, TH>(phase == 0 ? p.c1z : p.c1, blockIdx.x + phase * p.n1, 0, 1,
+                                                              plc_persist_tile);
+            if (phase < p.T) plc_grid_barrier(p.counter, (unsigned)(phase + 1) * gridDim.x);
+        }
+    } else {
+#pragma unroll 1
+        for (int phase = 0; phase <= p.T; ++phase) {
+            if (phase >= 1)
+                plc_conv_body<2, 4, 4, 3, STAGE_CB8, EPI, TH>(phase == 1 ? p.c2z : p.c2,
+                                                              (blockIdx.x - p.n1) + (phase - 1) * p.n2, 0, 1, plc_persist_tile);
+            if (phase < p.T) plc_grid_barrier(p.counter, (unsigned)(phase + 1) * gridDim.x);
+        }
+    }
+}
+
+// Launches the recurrence as one persistent kernel when both cells' tiles fit the chip at once (and
+// the widths are the instantiated [16,32]); *done tells the caller whether it did.
+template <int TH, bool SAVE>
+static int launch_persistent_th(PersistArgs p, int n_img, hipStream_t st, bool* done) {
+    constexpr int lds1 = plc_conv_lds_bytes<4, 3, TH, 1, STAGE_CB8>(), lds2 = plc_conv_lds_bytes<6, 3, TH, 1, STAGE_CB8>();
+    constexpr int lds = lds1 > lds2 ? lds1 : lds2;
+    auto kern = plc_lstm_persistent_kernel<TH, SAVE>;
+    if (lds > 65536) {
+        static bool lds_raised[64] = {false};
+        int rc = ensure_lds_limit((const void*)kern, lds, lds_raised);
+        if (rc) return rc;
+    }
+    for (ConvArgs* a : {&p.c1z, &p.c1, &p.c2z, &p.c2}) {
+        a->tiles_x = cdiv(a->W, 32);
+        a->tiles_y = cdiv(a->H, TH);
+        const long long per_step = (long long)n_img * a->tiles_x * a->tiles_y;
+        if (per_step * p.T >= (1ll << 31)) return PLC_OK;
+        a->n_tiles = (int)(per_step * p.T);          // tile numbers run over all steps
+        a->n_blocks = a->n_tiles;
+    }
+    p.n1 = p.c1.n_tiles / p.T;
+    p.n2 = p.c2.n_tiles / p.T;
+    const int grid = p.n1 + p.n2;
+    int per_cu = 0;
+    PLC_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)kern, 256, lds));
+    // Only grids that take at most a quarter of the chip's workgroup slots: the whole grid must be
+    // resident for the barrier to complete, and a second process (or stream) doing the same on this GPU
+    // must still find room for ITS whole grid.  Larger grids have launches long enough not to need this.
+    if (per_cu <= 0 || grid > per_cu * cu_count() / 4) return PLC_OK;
+    PLC_HIP(hipMemsetAsync(p.counter, 0, sizeof(unsigned), st));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, p);
+    PLC_HIP(hipGetLastError());
+    *done = true;
+    return PLC_OK;
+}
+
+static int launch_persistent(const PersistArgs& p, int n_img, bool save, hipStream_t st, bool* done) {
+    *done = false;
+    const long long t16 = (long long)n_img * cdiv(p.c1.H, 16) * cdiv(p.c1.W, 32);
+    // 16-row tiles when they still give every CU a workgroup of each cell, else 8-row tiles
+    if (t16 >= cu_count())
+        return save ? launch_persistent_th<16, true>(p, n_img, st, done) : launch_persistent_th<16, false>(p, n_img, st, done);
+    return save ? launch_persistent_th<8, true>(p, n_img, st, done) : launch_persistent_th<8, false>(p, n_img, st, done);
 }
 
 static int cell_fwd_cb8(const void* x, const void* h, const float* c_in, const void* wpk, const float* bpk,
@@ -469,6 +577,7 @@ struct RolloutPlan {
     size_t up_out[8];   // output of upsample block k
     size_t mid, fin;    // after residual resize / after target resize (== previous stage if unused)
     size_t dem_hr, lu_hr, dem_mid, lu_mid, gate_dem, gate_lu, gate, p0;
+    size_t sync;        // the persistent recurrence kernel's barrier counter
     size_t total;
     // derived sizes
     int up_H, up_W;     // size after the PixelShuffle blocks
@@ -543,6 +652,7 @@ static int rollout_plan(const plc_rollout_desc* d, RolloutPlan* p) {
     p->gate_lu = d->save_for_backward ? take((size_t)B * (C2 / 8) * ohw * 16) : (size_t)-1;
     p->gate = take((size_t)B * (C2 / 8) * ohw * 16);
     p->p0 = take((size_t)T * B * 4 * ohw * 16);
+    p->sync = take(256);
     p->total = o;
     return PLC_OK;
 }
@@ -711,10 +821,33 @@ extern "C" int plc_generator_rollout_fwd(const plc_rollout_desc* d, void* stream
         };
         // (Running cell 1 of step t+1 in the same launch as cell 2 of step t was measured: the two
         // kinds of workgroup share each SIMD's matrix pipe and finish together, so nothing is gained.)
-        for (int t = 0; t < T; ++t) {
-            if ((rc = launch_cell(cell1(t), B, C1, C1, st))) return rc;
-            if ((rc = launch_cell(cell2(t), B, C1, C2, st))) return rc;
+        bool persistent = false;
+        if (fast && T > 1 && !plc_no_persistent()) {
+            PersistArgs pa;
+            memset(&pa, 0, sizeof(pa));
+            auto stepped = [&](ConvArgs a, long long s_in0, long long s_h) {      // outer stride = one time step
+                a.src0.so = s_in0;
+                a.src1.so = s_h;
+                a.c_in.so = 2 * s_h;
+                a.out0.so = s_h;
+                a.out1.so = 2 * s_h;
+                a.out2.so = 4 * s_h;
+                return a;
+            };
+            pa.c1z = stepped(cell1(0), (long long)s1, (long long)s1);
+            pa.c2z = stepped(cell2(0), (long long)s1, (long long)s2);
+            pa.c1 = pa.c1z;
+            pa.c2 = pa.c2z;
+            pa.c1.zero_state = pa.c2.zero_state = 0;
+            pa.T = T;
+            pa.counter = (unsigned*)(ws + p.sync);
+            if ((rc = launch_persistent(pa, B, save, st, &persistent))) return rc;
         }
+        if (!persistent)
+            for (int t = 0; t < T; ++t) {
+                if ((rc = launch_cell(cell1(t), B, C1, C1, st))) return rc;
+                if ((rc = launch_cell(cell2(t), B, C1, C2, st))) return rc;
+            }
     }
 
     // ---- everything after the recurrence is batched over the T*B frames ----------------------

@@ -132,3 +132,49 @@ def test_edge_geometry_forward_and_grads(gpu, case):
     print(case, {k: (round(a, 4), round(b, 4)) for k, (a, b) in worst.items()})
     for k, (emax, el2) in worst.items():
         assert emax <= 3e-2 and el2 <= 3e-2, (k, emax, el2)
+
+
+@pytest.mark.parametrize("shape", [(2, 10, 64, 64, 1), (4, 10, 32, 32, 8), (1, 3, 20, 50, 2)])
+def test_single_launch_recurrence_vs_oracle(gpu, monkeypatch, shape):
+    """On small grids the whole recurrence (2 T cell steps) runs as ONE persistent launch whose
+    workgroups meet at a device-wide barrier between steps.  Checked against the oracle (forward and
+    parameter gradients, the bounds of test_edge_geometry_forward_and_grads), and bit for bit against
+    the per-step launches (PLC_NO_PERSISTENT=1), which run the same tile code."""
+    import os
+    from pl_convlstm_gan_amd import Generator
+    B, T, H, W, s = shape
+    torch.manual_seed(11)
+    m = Generator(hidden_dims=[16, 32], lu_channels=5, scale_factor=s).to(gpu)
+    gen = torch.Generator().manual_seed(12)
+    rain = 10 * torch.rand(B, T, 1, H, W, generator=gen) * (torch.rand(B, T, 1, H, W, generator=gen) > 0.5)
+    dem = torch.rand(B, 1, H * s, W * s, generator=gen)
+    lu = torch.rand(B, 5, H * s, W * s, generator=gen)
+    wgt = torch.rand(B, T, 1, H * s, W * s, generator=gen) + 0.5
+
+    def run():
+        for p in m.parameters():
+            p.grad = None
+        with torch.no_grad():
+            inf = m(rain.to(gpu), dem.to(gpu), lu.to(gpu)).clone()
+        out = m(rain.to(gpu), dem.to(gpu), lu.to(gpu))
+        (out * wgt.to(gpu)).sum().backward()
+        return inf, out.detach().clone(), {k: p.grad.clone() for k, p in m.named_parameters()}
+
+    monkeypatch.delenv("PLC_NO_PERSISTENT", raising=False)
+    inf_a, out_a, g_a = run()
+    monkeypatch.setenv("PLC_NO_PERSISTENT", "1")
+    inf_b, out_b, g_b = run()
+    monkeypatch.delenv("PLC_NO_PERSISTENT", raising=False)
+    assert torch.equal(inf_a, inf_b) and torch.equal(out_a, out_b) and torch.equal(inf_a, out_a)
+    for k in g_a:
+        assert torch.equal(g_a[k], g_b[k]), k
+
+    params = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    ref = O.generator_forward(params, rain, dem, lu, scale_factor=s)
+    leaf = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    emu = O.generator_forward(leaf, rain, dem, lu, scale_factor=s, emulate="bf16")
+    assert relmax(out_a.cpu(), ref) <= 2e-2
+    assert float((out_a.cpu() - emu.detach()).abs().max()) <= 4e-3 * float(ref.abs().max())
+    (emu * wgt).sum().backward()
+    for k, gr in g_a.items():
+        assert relmax(gr.cpu(), leaf[k].grad) <= 3e-2 and rel_l2(gr.cpu(), leaf[k].grad) <= 3e-2, k
