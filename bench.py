@@ -40,7 +40,7 @@ CONFIGS = {
     "c2": (8, 10, 128, 128, 1),    # configs[1]
     "c3": (4, 10, 256, 256, 1),    # configs[2] per-GPU shard (the shape the metric is quoted on)
     "c4": (4, 20, 256, 256, 1),    # configs[3] per-GPU shard (generator only)
-    "c5": (1, 10, 512, 512, 1),    # configs[4] per-GPU shard, run in bf16 (no fp8 gate conv is built)
+    "c5": (1, 10, 512, 512, 1),    # configs[4] per-GPU shard; its gate convs default to the fp8 (e4m3) path
     "p2": (4, 10, 32, 32, 8),      # default.yaml-faithful x8 downscaling to 256x256
 }
 FLOP_PER_PX_FWD = 171104          # algorithmic forward FLOPs per output pixel per frame (scale 1, L=5)
@@ -48,6 +48,7 @@ FWD_BYTES_PER_PX = 804            # algorithmic forward tensor traffic per pixel
 CELL2_FLOP_PER_PX = 2 * 55296     # cell-2 gate conv: (16+32)*9*128 MACs per pixel
 CELL2_BYTES_PER_PX = 416          # x 32 + h 64 + c 128 read, h' 64 + c' 128 written (bf16 h, fp32 c)
 PEAK_BF16 = 2.5e15                # dense bf16 MFMA peak of MI355X, FLOP/s
+PEAK_FP8 = 5.0e15                 # dense fp8 peak (block-scaled MFMA), FLOP/s
 PEAK_HBM = 8.0e12                 # HBM3E peak of MI355X, B/s
 # pointwise LSTM backward, per 8-channel unit of one pixel: two dh (bf16) 32 + dc' (fp32) 32 + c (fp32) 32
 # + gates i,f,o,g (bf16) 64 read; dz (bf16) 64 + dc (fp32) 32 written
@@ -88,6 +89,47 @@ def time_cell2_kernel(B, H, W, device, iters=50):
     def run():
         _lib.check(L.plc_convlstm_cell_fwd_cb8(x8.data_ptr(), h8.data_ptr(), c.data_ptr(), wpk.data_ptr(), bpk.data_ptr(),
                                                ho.data_ptr(), co.data_ptr(), None, B, 16, 32, H, W, st), "cell2")
+    for _ in range(5):
+        run()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(iters):
+        run()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e-3 / iters
+
+
+def time_cell2_kernel_fp8(B, H, W, device, iters=50):
+    """The same measurement for the fp8 (e4m3, block-scaled MFMA) cell-2 gate conv."""
+    from pl_convlstm_gan_amd import _lib, ops
+    L = _lib.lib()
+    hw = H * W
+    x = torch.randn(B, 16, H, W, device=device)
+    h = torch.tanh(torch.randn(B, 32, H, W, device=device))
+    st = ops._stream()
+    x8 = torch.empty(B, 1, H, W, 16, dtype=torch.uint8, device=device)
+    h8 = torch.empty(B, 2, H, W, 16, dtype=torch.uint8, device=device)
+    _lib.check(L.plc_cb8_bf16_to_cb16_fp8(ops.to_cb8_bf16(x).data_ptr(), x8.data_ptr(), B, 16, H, W, st), "fp8 x")
+    _lib.check(L.plc_cb8_bf16_to_cb16_fp8(ops.to_cb8_bf16(h).data_ptr(), h8.data_ptr(), B, 32, H, W, st), "fp8 h")
+    c = torch.randn(B * 32 * hw, device=device)
+    w = 0.05 * torch.randn(128, 48, 3, 3, device=device)
+    b = torch.zeros(128, device=device)
+    wpk16 = torch.empty(L.plc_packed_weight_bytes(128, 16, 32, 3), dtype=torch.uint8, device=device)
+    bpk = torch.empty(L.plc_packed_bias_bytes(128), dtype=torch.uint8, device=device)
+    _lib.check(L.plc_pack_conv_weight(w.data_ptr(), b.data_ptr(), wpk16.data_ptr(), bpk.data_ptr(), 128, 16, 32, 3, 1, st), "pack")
+    wpk = torch.empty(L.plc_fp8_packed_weight_bytes(16, 32), dtype=torch.uint8, device=device)
+    sw = torch.zeros(2, dtype=torch.int32, device=device)
+    _lib.check(L.plc_pack_lstm_weight_fp8(w.data_ptr(), wpk.data_ptr(), sw.data_ptr(), 16, 32, st), "pack fp8")
+    ho = torch.empty(B, 4, H, W, 8, dtype=torch.int16, device=device)
+    h8o = torch.empty_like(h8)
+    co = torch.empty_like(c)
+
+    def run():
+        _lib.check(L.plc_convlstm_cell_fwd_fp8(x8.data_ptr(), h8.data_ptr(), c.data_ptr(), wpk.data_ptr(), sw.data_ptr(),
+                                               bpk.data_ptr(), ho.data_ptr(), h8o.data_ptr(), co.data_ptr(), None,
+                                               B, 16, 32, H, W, st), "cell2 fp8")
     for _ in range(5):
         run()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -187,6 +229,8 @@ def main():
                          "default: the config's per-GPU batch on every rank (weak scaling)")
     ap.add_argument("--hidden", default="16,32", help="hidden_dims of the generator (the benchmark configs use 16,32; "
                     "32,64 is the reference's class default and runs on the run-time-width kernels)")
+    ap.add_argument("--gate-dtype", default=None, choices=["bf16", "fp8"],
+                    help="operand type of the two gate convs (default: fp8 for c5, BASELINE configs[4]; bf16 otherwise)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
     if args.gpus < 1:
@@ -243,6 +287,8 @@ def main():
     model = Generator(hidden_dims=hidden, lu_channels=5, scale_factor=s)
     rain, dem, lu, coords, values = synthetic(B, T, H, W, s, 1234 + rank, device)
     model = model.to(device)
+    gate_dtype = args.gate_dtype or ("fp8" if args.config == "c5" and hidden == [16, 32] else "bf16")
+    model.gate_dtype = gate_dtype
     with torch.no_grad():
         model(rain[:1, :1].contiguous(), dem[:1].contiguous(), lu[:1].contiguous())   # materialise lazy blocks
     loss_module = CombinedLoss()
@@ -299,9 +345,10 @@ def main():
                       else "predicted frames/sec (whole node)",
             "value": frames / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
-            "dtype": "bf16", "data": "synthetic",
+            "dtype": gate_dtype if gate_dtype == "fp8" else "bf16", "data": "synthetic",
             "config": {"workload": f"{args.config}: {what}, B={B}/GPU, T={T}, {H}x{W} -> {H * s}x{W * s}, 1 channel, "
-                                   f"hidden [{args.hidden}], L=5, scale_factor={s}, {N_STATIONS} stations",
+                                   f"hidden [{args.hidden}], L=5, scale_factor={s}, {N_STATIONS} stations, gate convs {gate_dtype}"
+                                   + (" (e4m3 operands, fp32 accumulate; every other conv and the backward pass bf16)" if gate_dtype == "fp8" else ""),
                        "global_batch": world * B, "T": T, "mode": args.mode,
                        "parallelism": f"dp{world} (batch sharded; one flat-gradient all-reduce per step)"},
             "fwd_frames_per_s": world * B * T * n_fwd / dt_fwd,
@@ -316,18 +363,24 @@ def main():
             res["fwd_mfma_frac"] = fwd_flop / (dt_fwd / n_fwd) / (world * PEAK_BF16)
             res["fwd_hbm_frac"] = FWD_BYTES_PER_PX * px * world * B * T / (dt_fwd / n_fwd) / (world * PEAK_HBM)
         # dominant kernel: cell-2 gate conv, one launch per timestep
-        tk = time_cell2_kernel(B, H, W, device)
+        fp8 = gate_dtype == "fp8"
+        tk = time_cell2_kernel_fp8(B, H, W, device) if fp8 else time_cell2_kernel(B, H, W, device)
         flops = CELL2_FLOP_PER_PX * B * H * W
         traffic = None
         tj = os.path.join(ROOT, "profiles", "r1_cell2_traffic.json")
         if os.path.exists(tj) and args.config == "c3":
             traffic = json.load(open(tj)).get("hbm_bytes_per_launch")
-        mfma_roof = {"bound": "mfma", "kernel": "plc_conv_mfma_kernel<2,4,4,3,CB8,LSTM> (cell-2 gate conv + LSTM epilogue)",
-                     "achieved": flops / tk / 1e12, "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
-                     "frac": flops / tk / PEAK_BF16, "traffic": traffic,
+        peak = PEAK_FP8 if fp8 else PEAK_BF16
+        # fp8 operands: x 16 + h 32 bytes per pixel read (instead of 32 + 64), h' written twice (bf16 64 + fp8 32)
+        cell_bytes = (CELL2_BYTES_PER_PX - 48 + 32) if fp8 else CELL2_BYTES_PER_PX
+        mfma_roof = {"bound": "mfma",
+                     "kernel": ("plc_lstm_fp8_kernel<1,2,4> (cell-2 gate conv, e4m3 on v_mfma_scale_f32_32x32x64_f8f6f4, + LSTM epilogue)"
+                                if fp8 else "plc_conv_mfma_kernel<2,4,4,3,CB8,LSTM> (cell-2 gate conv + LSTM epilogue)"),
+                     "achieved": flops / tk / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s",
+                     "frac": flops / tk / peak, "traffic": None if fp8 else traffic,
                      "launch_us": tk * 1e6, "flop_per_launch": flops,
-                     "alg_bytes_per_launch": CELL2_BYTES_PER_PX * B * H * W,
-                     "hbm_frac": CELL2_BYTES_PER_PX * B * H * W / tk / PEAK_HBM}
+                     "alg_bytes_per_launch": cell_bytes * B * H * W,
+                     "hbm_frac": cell_bytes * B * H * W / tk / PEAK_HBM}
         if args.mode == "train":
             # the kernel with the largest share of a train step is the HBM-bound pointwise LSTM
             # backward (2T launches); the cell-2 conv, top kernel of the forward, follows as roofline_mfma

@@ -90,6 +90,25 @@ int plc_convlstm_cell_fwd(const float* x, const float* h, const float* c,
                           int B, int Cin, int Ch, int H, int W, void* stream);
 
 /* ---------------------------------------------------------------------------------------
+ * ConvLSTM cell forward with fp8 gate-conv operands.  Same arithmetic as plc_convlstm_cell_fwd_cb8
+ * (convlstm.py:16-28) with x, h and the conv weights rounded to OCP e4m3 (fp32 accumulation, fp32 cell
+ * state, fp32 bias), on v_mfma_scale_f32_32x32x64_f8f6f4.  The reference computes in fp32; the stated
+ * tolerance of this path is in the tests (tests/test_gpu_fp8.py).
+ *   x8, h8:    fp8 "CB16" [B][C/16][H][W][16] (plc_cb8_bf16_to_cb16_fp8 converts a bf16 CB8 tensor)
+ *   wpk8, scale_word: plc_pack_lstm_weight_fp8 (weights scaled by a power of two taken from max|w|, the
+ *              instruction's block-scale operand undoes it; scale_word is 2 ints)
+ *   bpk:       packed bias of plc_pack_conv_weight(mode = PLC_PACK_LSTM)
+ *   h_out (bf16 CB8), h8_out (fp8 CB16, the next step's operand), c_out (fp32 CB8), gates (NULL or bf16 CB8)
+ * Supported: (Cin, Ch) in {(16,16), (16,32)}.
+ * ------------------------------------------------------------------------------------- */
+size_t plc_fp8_packed_weight_bytes(int Cin, int Ch);
+int plc_pack_lstm_weight_fp8(const float* w, void* wpk8, int* scale_word, int Cin, int Ch, void* stream);
+int plc_cb8_bf16_to_cb16_fp8(const void* src_cb8, void* dst_cb16, int N, int C, int H, int W, void* stream);
+int plc_convlstm_cell_fwd_fp8(const void* x8, const void* h8, const float* c_in, const void* wpk8,
+                              const int* scale_word, const float* bpk, void* h_out, void* h8_out,
+                              float* c_out, void* gates, int B, int Cin, int Ch, int H, int W, void* stream);
+
+/* ---------------------------------------------------------------------------------------
  * ConvLSTM cell forward without any allocation.  This entry point has no counterpart in the
  * reference: it exists for callers that cannot allocate device memory -- code under HIP graph
  * capture, tight serving loops, harnesses that forbid hipMalloc -- and therefore cannot bring the
@@ -134,6 +153,7 @@ typedef struct plc_rollout_desc {
     float mid_scale_h, mid_scale_w;   /* source/destination coordinate scales of the residual resize */
     float out_scale_h, out_scale_w;   /* ... of the resize to target_size */
     int save_for_backward;   /* keep gate activations in the workspace */
+    int gate_fp8;            /* 1: the two gate convs take fp8 (e4m3) operands (hidden_dims [16,32] only); 0: bf16 */
     /* inputs (fp32, device) */
     const float* rain;
     const float* dem;

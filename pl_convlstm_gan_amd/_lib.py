@@ -17,6 +17,7 @@ EXPORTS = (
     "plc_packed_weight_bytes", "plc_packed_bias_bytes", "plc_pack_conv_weight",
     "plc_convlstm_cell_fwd_cb8", "plc_convlstm_cell_workspace_bytes", "plc_convlstm_cell_fwd",
     "plc_convlstm_cell_noalloc_max_bytes", "plc_convlstm_cell_fwd_noalloc",
+    "plc_fp8_packed_weight_bytes", "plc_pack_lstm_weight_fp8", "plc_cb8_bf16_to_cb16_fp8", "plc_convlstm_cell_fwd_fp8",
     "plc_generator_workspace_bytes", "plc_generator_rollout_fwd", "plc_generator_workspace_offset",
     "plc_convlstm_cell_bwd_workspace_bytes", "plc_convlstm_cell_bwd", "plc_lstm_pointwise_bwd",
     "plc_generator_bwd_workspace_bytes", "plc_generator_rollout_bwd",
@@ -36,7 +37,7 @@ class RolloutDesc(C.Structure):
         ("n_blocks", C.c_int), ("mid_H", C.c_int), ("mid_W", C.c_int), ("out_H", C.c_int), ("out_W", C.c_int),
         ("mid_scale_h", C.c_float), ("mid_scale_w", C.c_float),
         ("out_scale_h", C.c_float), ("out_scale_w", C.c_float),
-        ("save_for_backward", C.c_int),
+        ("save_for_backward", C.c_int), ("gate_fp8", C.c_int),
         ("rain", _f), ("dem", _f), ("lu", _f), ("row_tab", _f), ("col_tab", _f),
         ("init_w", _f), ("init_b", _f), ("cell1_w", _f), ("cell1_b", _f), ("cell2_w", _f), ("cell2_b", _f),
         ("dem0_w", _f), ("dem0_b", _f), ("dem2_w", _f), ("dem2_b", _f),
@@ -116,6 +117,14 @@ def lib():
     L.plc_convlstm_cell_noalloc_max_bytes.argtypes = []
     L.plc_convlstm_cell_fwd_noalloc.restype = i
     L.plc_convlstm_cell_fwd_noalloc.argtypes = [p, p, p, p, p, p, p, i, i, i, i, i, p]
+    L.plc_fp8_packed_weight_bytes.restype = sz
+    L.plc_fp8_packed_weight_bytes.argtypes = [i, i]
+    L.plc_pack_lstm_weight_fp8.restype = i
+    L.plc_pack_lstm_weight_fp8.argtypes = [p, p, p, i, i, p]
+    L.plc_cb8_bf16_to_cb16_fp8.restype = i
+    L.plc_cb8_bf16_to_cb16_fp8.argtypes = [p, p, i, i, i, i, p]
+    L.plc_convlstm_cell_fwd_fp8.restype = i
+    L.plc_convlstm_cell_fwd_fp8.argtypes = [p] * 10 + [i, i, i, i, i, p]
     L.plc_generator_workspace_bytes.restype = sz
     L.plc_generator_workspace_bytes.argtypes = [C.POINTER(RolloutDesc)]
     L.plc_generator_rollout_fwd.restype = i

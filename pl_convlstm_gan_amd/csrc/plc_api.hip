@@ -11,6 +11,7 @@
 #include "plc_conv_kernel.h"
 #include "plc_convg_kernel.h"
 #include "plc_misc_kernels.h"
+#include "plc_fp8_kernels.h"
 
 // ---------------------------------------------------------------------------------------------
 // errors
@@ -517,6 +518,92 @@ extern "C" int plc_convlstm_cell_fwd(const float* x, const float* h, const float
 }
 
 // ---------------------------------------------------------------------------------------------
+// fp8 (e4m3) gate convolution
+// ---------------------------------------------------------------------------------------------
+static inline int fp8_nks(int Cin, int Ch) { return (9 * ((Cin + Ch) / 16) + 3) / 4; }
+static inline bool fp8_supported(int Cin, int Ch) { return Cin == 16 && (Ch == 16 || Ch == 32); }
+
+extern "C" size_t plc_fp8_packed_weight_bytes(int Cin, int Ch) {
+    if (!fp8_supported(Cin, Ch)) return 0;
+    return align256((size_t)(Ch / 8) * fp8_nks(Cin, Ch) * 64 * 32);
+}
+
+static int pack_lstm_fp8_pair(const float* w1, void* wpk1, int* sw1, int Cin1, int Ch1, const float* w2, void* wpk2,
+                              int* sw2, int Cin2, int Ch2, hipStream_t st) {
+    PackFp8Job j0 = {w1, (unsigned*)wpk1, sw1, Cin1, Ch1};
+    PackFp8Job j1 = {w2, (unsigned*)wpk2, sw2, Cin2, Ch2};
+    hipLaunchKernelGGL(plc_pack_lstm_fp8_kernel, dim3(w2 ? 2 : 1), dim3(1024), 0, st, j0, j1);
+    PLC_HIP(hipGetLastError());
+    return PLC_OK;
+}
+
+extern "C" int plc_pack_lstm_weight_fp8(const float* w, void* wpk8, int* scale_word, int Cin, int Ch, void* stream) {
+    PLC_REQUIRE(w && wpk8 && scale_word, "plc_pack_lstm_weight_fp8: null pointer");
+    PLC_REQUIRE(aligned16(wpk8), "plc_pack_lstm_weight_fp8: packed buffer must be 16-byte aligned");
+    if (!fp8_supported(Cin, Ch))
+        return plc_fail(PLC_EUNSUPPORTED, "fp8 gate conv (Cin=%d, Ch=%d) is compiled for {(16,16), (16,32)} only", Cin, Ch);
+    return pack_lstm_fp8_pair(w, wpk8, scale_word, Cin, Ch, nullptr, nullptr, nullptr, 0, 0, (hipStream_t)stream);
+}
+
+extern "C" int plc_cb8_bf16_to_cb16_fp8(const void* src_cb8, void* dst_cb16, int N, int C, int H, int W, void* stream) {
+    PLC_REQUIRE(src_cb8 && dst_cb16 && N > 0 && C > 0 && H > 0 && W > 0, "plc_cb8_bf16_to_cb16_fp8: bad argument");
+    PLC_REQUIRE(aligned16(src_cb8) && aligned16(dst_cb16), "plc_cb8_bf16_to_cb16_fp8: pointers must be 16-byte aligned");
+    const int ncb = cdiv(C, 8);
+    const long long total = (long long)N * cdiv(ncb, 2) * H * W;
+    hipLaunchKernelGGL(plc_cb8_to_cb16_fp8_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream,
+                       (const uint4*)src_cb8, (uint4*)dst_cb16, (long long)N, ncb, (long long)H * W);
+    PLC_HIP(hipGetLastError());
+    return PLC_OK;
+}
+
+template <int NU0, int NU1, int NMT, int TH>
+static int launch_cell_fp8_th(Fp8CellArgs fa, int B, hipStream_t st) {
+    fa.c.tiles_x = cdiv(fa.c.W, 32);
+    fa.c.tiles_y = cdiv(fa.c.H, TH);
+    fa.c.n_tiles = B * fa.c.tiles_x * fa.c.tiles_y;
+    fa.c.n_blocks = fa.c.n_tiles;
+    constexpr int lds = plc_fp8_lds_bytes<NU0, NU1, NMT, TH>();
+    static_assert(lds <= 65536, "fp8 cell tile exceeds the default dynamic LDS limit");
+    if (fa.c.save_gates)
+        hipLaunchKernelGGL((plc_lstm_fp8_kernel<NU0, NU1, NMT, TH, true>), dim3(fa.c.n_tiles), dim3(256), lds, st, fa);
+    else
+        hipLaunchKernelGGL((plc_lstm_fp8_kernel<NU0, NU1, NMT, TH, false>), dim3(fa.c.n_tiles), dim3(256), lds, st, fa);
+    PLC_HIP(hipGetLastError());
+    return PLC_OK;
+}
+
+// a = the bf16 cell's arguments with src0 / src1 pointing at the fp8 CB16 copies of x / h and wpk at the fp8 fragments
+static int launch_cell_fp8(const ConvArgs& a, void* h8_out, const int* scale_word, int B, int Cin, int Ch, hipStream_t st) {
+    Fp8CellArgs fa;
+    memset(&fa, 0, sizeof(fa));
+    fa.c = a;
+    const long long hw = (long long)a.H * a.W;
+    fa.c.src0 = tens(a.src0.p, (Cin / 16) * hw * 16, 0);
+    fa.c.src1 = tens(a.src1.p, (Ch / 16) * hw * 16, 0);
+    fa.h8_out = tens(h8_out, (Ch / 16) * hw * 16, 0);
+    fa.scale_word = scale_word;
+    const long long t16 = (long long)B * cdiv(a.H, 16) * cdiv(a.W, 32);
+    if (Cin == 16 && Ch == 16)
+        return t16 >= 512 ? launch_cell_fp8_th<1, 1, 2, 16>(fa, B, st) : launch_cell_fp8_th<1, 1, 2, 8>(fa, B, st);
+    if (Cin == 16 && Ch == 32)
+        return t16 >= 512 ? launch_cell_fp8_th<1, 2, 4, 16>(fa, B, st) : launch_cell_fp8_th<1, 2, 4, 8>(fa, B, st);
+    return plc_fail(PLC_EUNSUPPORTED, "fp8 gate conv (Cin=%d, Ch=%d) is compiled for {(16,16), (16,32)} only", Cin, Ch);
+}
+
+extern "C" int plc_convlstm_cell_fwd_fp8(const void* x8, const void* h8, const float* c_in, const void* wpk8,
+                                         const int* scale_word, const float* bpk, void* h_out, void* h8_out,
+                                         float* c_out, void* gates, int B, int Cin, int Ch, int H, int W, void* stream) {
+    PLC_REQUIRE(x8 && h8 && c_in && wpk8 && scale_word && bpk && h_out && h8_out && c_out,
+                "plc_convlstm_cell_fwd_fp8: null pointer");
+    PLC_REQUIRE(B > 0 && H > 0 && W > 0, "plc_convlstm_cell_fwd_fp8: non-positive size");
+    PLC_REQUIRE(aligned16(x8) && aligned16(h8) && aligned16(c_in) && aligned16(wpk8) && aligned16(bpk) &&
+                    aligned16(h_out) && aligned16(h8_out) && aligned16(c_out) && aligned16(gates),
+                "plc_convlstm_cell_fwd_fp8: pointers must be 16-byte aligned");
+    const ConvArgs a = cell_conv_args(x8, h8, c_in, wpk8, bpk, h_out, c_out, gates, B, Cin, Ch, H, W);
+    return launch_cell_fp8(a, h8_out, scale_word, B, Cin, Ch, (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------------------------------------
 // ConvLSTM cell forward for callers that cannot allocate: the staging area is a fixed array in the
 // library's own device image instead of a caller workspace.
 // ---------------------------------------------------------------------------------------------
@@ -578,6 +665,8 @@ struct RolloutPlan {
     size_t mid, fin;    // after residual resize / after target resize (== previous stage if unused)
     size_t dem_hr, lu_hr, dem_mid, lu_mid, gate_dem, gate_lu, gate, p0;
     size_t sync;        // the persistent recurrence kernel's barrier counter
+    // fp8 gate convs (desc.gate_fp8): fp8 copies of the cells' operands, fp8 weight fragments, scale words
+    size_t xs8, h1s8, h2s8, cell1_w8, cell2_w8, scale8;
     size_t total;
     // derived sizes
     int up_H, up_W;     // size after the PixelShuffle blocks
@@ -653,6 +742,18 @@ static int rollout_plan(const plc_rollout_desc* d, RolloutPlan* p) {
     p->gate = take((size_t)B * (C2 / 8) * ohw * 16);
     p->p0 = take((size_t)T * B * 4 * ohw * 16);
     p->sync = take(256);
+    if (d->gate_fp8) {
+        if (!widths_fast(C1, C2))
+            return plc_fail(PLC_EUNSUPPORTED, "rollout: the fp8 gate conv is compiled for hidden_dims=[16,32] only (got [%d,%d])", C1, C2);
+        p->xs8 = take((size_t)T * B * (C1 / 16) * hw * 16);
+        p->h1s8 = take((size_t)(T + 1) * B * (C1 / 16) * hw * 16);
+        p->h2s8 = take((size_t)(T + 1) * B * (C2 / 16) * hw * 16);
+        p->cell1_w8 = take(plc_fp8_packed_weight_bytes(C1, C1));
+        p->cell2_w8 = take(plc_fp8_packed_weight_bytes(C1, C2));
+        p->scale8 = take(256);
+    } else {
+        p->xs8 = p->h1s8 = p->h2s8 = p->cell1_w8 = p->cell2_w8 = p->scale8 = (size_t)-1;
+    }
     p->total = o;
     return PLC_OK;
 }
@@ -822,7 +923,28 @@ extern "C" int plc_generator_rollout_fwd(const plc_rollout_desc* d, void* stream
         // (Running cell 1 of step t+1 in the same launch as cell 2 of step t was measured: the two
         // kinds of workgroup share each SIMD's matrix pipe and finish together, so nothing is gained.)
         bool persistent = false;
-        if (fast && T > 1 && !plc_no_persistent()) {
+        if (d->gate_fp8) {
+            // fp8 operands for the two gate convs: the stem output is converted once for all frames, every
+            // cell launch writes h' as bf16 (post conv, backward pass) and as fp8 (the next gate convs)
+            const size_t s1f = (size_t)B * (C1 / 16) * hw * 16, s2f = (size_t)B * (C2 / 16) * hw * 16;
+            if ((rc = pack_lstm_fp8_pair(d->cell1_w, ws + p.cell1_w8, (int*)(ws + p.scale8), C1, C1, d->cell2_w,
+                                         ws + p.cell2_w8, (int*)(ws + p.scale8) + 8, C1, C2, st)))
+                return rc;
+            if ((rc = plc_cb8_bf16_to_cb16_fp8(ws + p.xs, ws + p.xs8, T * B, C1, H, W, stream))) return rc;
+            for (int t = 0; t < T; ++t) {
+                ConvArgs a1 = cell1(t);
+                a1.src0.p = ws + p.xs8 + t * s1f;
+                a1.src1.p = ws + p.h1s8 + t * s1f;
+                a1.wpk = (const uint4*)(ws + p.cell1_w8);
+                if ((rc = launch_cell_fp8(a1, ws + p.h1s8 + (t + 1) * s1f, (const int*)(ws + p.scale8), B, C1, C1, st))) return rc;
+                ConvArgs a2 = cell2(t);
+                a2.src0.p = ws + p.h1s8 + (t + 1) * s1f;
+                a2.src1.p = ws + p.h2s8 + t * s2f;
+                a2.wpk = (const uint4*)(ws + p.cell2_w8);
+                if ((rc = launch_cell_fp8(a2, ws + p.h2s8 + (t + 1) * s2f, (const int*)(ws + p.scale8) + 8, B, C1, C2, st))) return rc;
+            }
+            persistent = true;      // (the recurrence has run)
+        } else if (fast && T > 1 && !plc_no_persistent()) {
             PersistArgs pa;
             memset(&pa, 0, sizeof(pa));
             auto stepped = [&](ConvArgs a, long long s_in0, long long s_h) {      // outer stride = one time step

@@ -134,6 +134,10 @@ __global__ __launch_bounds__(256, 2) void plc_convg_kernel(const ConvArgs a) {
     }
 
     if (!active) return;
+    // (the epilogues test image bounds per lane; the accumulators are pinned here so that no MFMA, which
+    // takes its A rows from all 64 lanes, can be moved under that divergent test)
+#pragma unroll
+    for (int r = 0; r < TH; ++r) asm volatile("" : "+v"(acc[r]));
 #pragma unroll
     for (int r = 0; r < TH; ++r) {
         if (r < rows) {

@@ -131,6 +131,9 @@ class Generator(nn.Module):
         )
         self._in_channels = in_channels
         self._dem_channels = dem_channels
+        # operand type of the two gate convolutions: "bf16", or "fp8" (e4m3 operands on the block-scaled
+        # matrix instruction; hidden_dims [16,32] only).  Not a constructor argument: the reference has none.
+        self.gate_dtype = "bf16"
         self._ws = {}
         self._tabs = {}
 
@@ -216,6 +219,9 @@ class Generator(nn.Module):
             raise RuntimeError(
                 f"The size of tensor a ({d.out_W}) must match the size of tensor b ({fW}) at non-singleton dimension 3")
         d.save_for_backward = 1 if save_for_backward else 0
+        if self.gate_dtype not in ("bf16", "fp8"):
+            raise ValueError(f"gate_dtype must be 'bf16' or 'fp8', not {self.gate_dtype!r}")
+        d.gate_fp8 = 1 if self.gate_dtype == "fp8" else 0
         return d, (fH, fW)
 
     def _bind(self, d, rain_lr, dem, lu, out, params):
@@ -245,7 +251,7 @@ class Generator(nn.Module):
         L = _lib.lib()
         nbytes = L.plc_generator_workspace_bytes(C.byref(d))
         if nbytes == 0:
-            _lib.check(-2 if "hidden_dims" in L.plc_last_error().decode() else -1, "Generator.forward")
+            _lib.check(-2 if ("hidden_dims" in L.plc_last_error().decode()) else -1, "Generator.forward")
         if fresh:
             # training: the workspace holds the activations saved for backward and is owned by
             # the autograd node, so a second forward cannot overwrite it

@@ -63,8 +63,9 @@ def _dp_active(group=None) -> bool:
 
 def _all_reduce(t: torch.Tensor, op, group=None) -> torch.Tensor:
     """dist.all_reduce in place.  With the gloo backend and a GPU tensor the reduction goes through
-    a host copy (gloo's own GPU path deadlocks when several ranks share one GPU, which is how the
-    multi-process control flow is rehearsed on a one-GPU box); RCCL reduces the GPU tensor directly."""
+    a host copy: gloo is only the rehearsal backend (several ranks sharing one GPU on a one-GPU box),
+    a rehearsal with gloo collectives on GPU tensors once hung without a diagnosis, and a host
+    all-reduce has no GPU dependency by construction.  RCCL reduces the GPU tensor directly."""
     if t.is_cuda and dist.get_backend(group) == "gloo":
         host = t.detach().cpu()
         dist.all_reduce(host, op=op, group=group)
