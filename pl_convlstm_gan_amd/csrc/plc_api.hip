@@ -532,7 +532,7 @@ static int pack_lstm_fp8_pair(const float* w1, void* wpk1, int* sw1, int Cin1, i
                               int* sw2, int Cin2, int Ch2, hipStream_t st) {
     PackFp8Job j0 = {w1, (unsigned*)wpk1, sw1, Cin1, Ch1};
     PackFp8Job j1 = {w2, (unsigned*)wpk2, sw2, Cin2, Ch2};
-    hipLaunchKernelGGL(plc_pack_lstm_fp8_kernel, dim3(w2 ? 2 : 1), dim3(1024), 0, st, j0, j1);
+    hipLaunchKernelGGL(plc_pack_lstm_fp8_kernel, dim3((w2 ? 2 : 1) * PLC_FP8_PACK_BLOCKS), dim3(1024), 0, st, j0, j1);
     PLC_HIP(hipGetLastError());
     return PLC_OK;
 }

@@ -56,9 +56,11 @@ __global__ void plc_cb8_to_cb16_fp8_kernel(const uint4* __restrict__ src, uint4*
 }
 
 // Gate-conv weights fp32 [4Ch][Cin+Ch][3][3] -> fp8 A fragments [M tile][k-step][lane][32 bytes] and the
-// scale word.  ONE workgroup of 1024 threads per conv (the tensors are small): pass 1 finds max|w|,
-// pass 2 scales, rounds and scatters.  scale_word[0] = the E8M0 byte of 2^-e replicated four times (the
-// instruction's scale operand), scale_word[1] = e.
+// scale word.  PLC_FP8_PACK_BLOCKS workgroups of 1024 threads per conv: every workgroup finds max|w| of
+// the whole tensor by itself (a few hundred KB from L2; cheaper than a second launch or a grid-wide
+// reduction) and then scales, rounds and scatters its share of the fragments.  scale_word[0] = the E8M0
+// byte of 2^-e replicated four times (the instruction's scale operand), scale_word[1] = e.
+constexpr int PLC_FP8_PACK_BLOCKS = 16;
 struct PackFp8Job {
     const float* w;
     unsigned* wpk;
@@ -66,7 +68,8 @@ struct PackFp8Job {
     int Cin, Ch;
 };
 __global__ __launch_bounds__(1024) void plc_pack_lstm_fp8_kernel(const PackFp8Job j0, const PackFp8Job j1) {
-    const PackFp8Job jb = blockIdx.x == 0 ? j0 : j1;
+    const PackFp8Job jb = blockIdx.x < PLC_FP8_PACK_BLOCKS ? j0 : j1;
+    const int part = blockIdx.x % PLC_FP8_PACK_BLOCKS;
     __shared__ float red[16];
     __shared__ int e_sh;
     const int cout = 4 * jb.Ch, cin = jb.Cin + jb.Ch, nu = cin / 16;
@@ -85,13 +88,15 @@ __global__ __launch_bounds__(1024) void plc_pack_lstm_fp8_kernel(const PackFp8Jo
         int e = (mm > 0.0f && isfinite(mm)) ? 134 - E : 0;
         e = e > 100 ? 100 : (e < -100 ? -100 : e);
         e_sh = e;
-        jb.scale_word[0] = 0x01010101 * (127 - e);
-        jb.scale_word[1] = e;
+        if (part == 0) {
+            jb.scale_word[0] = 0x01010101 * (127 - e);
+            jb.scale_word[1] = e;
+        }
     }
     __syncthreads();
     const float mul = __builtin_ldexpf(1.0f, e_sh);
     const long long total = (long long)n_mt * nks * 64 * 8;           // dwords: 4 fp8 each
-    for (long long idx = threadIdx.x; idx < total; idx += 1024) {
+    for (long long idx = part * 1024 + threadIdx.x; idx < total; idx += 1024 * PLC_FP8_PACK_BLOCKS) {
         const int d = idx & 7;                                         // dword inside the lane's 32 bytes
         const int lane = (idx >> 3) & 63;
         const int s = (idx >> 9) % nks;

@@ -227,10 +227,24 @@ __global__ __launch_bounds__(LOSS_FIN_THREADS) void plc_loss_finalize_kernel(con
     __shared__ float red6[6][LOSS_FIN_THREADS / 64];
     __shared__ float sh_k;
     __shared__ int pix[LOSS_PIX_CACHE];
+    __shared__ int nxt[LOSS_PIX_CACHE];      // next station (in order) on the same pixel, or -1; bit 30: not the first on it
     const int tid = threadIdx.x;
     for (int n = tid; n < a.N && n < LOSS_PIX_CACHE; n += LOSS_FIN_THREADS) {
         int r, c;
         pix[n] = plc_gauge_pixel(a, n, r, c) ? r * a.Wh + c : -1;
+    }
+    __syncthreads();
+    // Stations sharing a pixel, found ONCE per call (N^2 / 1024 probes per thread) instead of once per
+    // frame: the gradient pass below then walks each pixel's chain of stations.
+    const bool chains = a.dpred != nullptr && a.N <= LOSS_PIX_CACHE;
+    if (chains) {
+        for (int n = tid; n < a.N; n += LOSS_FIN_THREADS) {
+            const int o = pix[n];
+            int next = -1, later = 0;
+            for (int m = n + 1; m < a.N && next < 0; ++m) next = pix[m] == o ? m : -1;
+            for (int m = 0; m < n && !later; ++m) later = pix[m] == o;
+            nxt[n] = (next < 0 ? 0x3fffffff : next) | (later ? 0x40000000 : 0);
+        }
     }
     // fixed-order sums of the block partials
     float s[4] = {0.f, 0.f, 0.f, 0.f};
@@ -296,17 +310,27 @@ __global__ __launch_bounds__(LOSS_FIN_THREADS) void plc_loss_finalize_kernel(con
         const int o = plc_gauge_offset(a, pix, n);
         if (o < 0) continue;
         bool first = true;
-        for (int m = 0; m < n && first; ++m) first = plc_gauge_offset(a, pix, m) != o;
+        if (chains) first = (nxt[n] & 0x40000000) == 0;
+        else for (int m = 0; m < n && first; ++m) first = plc_gauge_offset(a, pix, m) != o;
         if (!first) continue;
         const int b = f / a.T, t = f % a.T;
         const float* vals = a.values + ((long long)(a.values_per_batch ? b : 0) * a.T + t) * a.N;
         const float pv = a.pred[(long long)f * plane + o];
         float g = a.dpred[(long long)f * plane + o];
-        for (int m = n; m < a.N; ++m) {
-            if (plc_gauge_offset(a, pix, m) != o) continue;
-            const float obs = vals[m];
-            if (obs != obs) continue;
-            g += k * plc_gauge_weight(obs, a.weight_mode) * plc_sgn(pv - obs);
+        if (chains) {
+            for (int m = n; m >= 0;) {           // this pixel's stations, in station order (same sums as the scan)
+                const float obs = vals[m];
+                if (obs == obs) g += k * plc_gauge_weight(obs, a.weight_mode) * plc_sgn(pv - obs);
+                const int link = nxt[m] & 0x3fffffff;
+                m = link == 0x3fffffff ? -1 : link;
+            }
+        } else {
+            for (int m = n; m < a.N; ++m) {
+                if (plc_gauge_offset(a, pix, m) != o) continue;
+                const float obs = vals[m];
+                if (obs != obs) continue;
+                g += k * plc_gauge_weight(obs, a.weight_mode) * plc_sgn(pv - obs);
+            }
         }
         a.dpred[(long long)f * plane + o] = g;
     }

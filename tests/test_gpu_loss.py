@@ -125,3 +125,25 @@ def test_fused_loss_bit_repeatable_at_bench_size(gpu):
     assert runs[0][0] == runs[1][0] and torch.equal(runs[0][1], runs[1][1])
     _, to, _ = _oracle(pred, lr, coords, values, 1.0, [1.0, 1.0, 0.1, 0.05], True, "log")
     assert _close(float(runs[0][0]), float(to))
+
+
+@pytest.mark.parametrize("N", [1500, 2500])
+def test_fused_loss_many_gauges_on_few_pixels(gpu, N):
+    """Thousands of gauges on a 6x5 grid: every pixel carries a long chain of stations (N = 1500: the
+    chains found once per call; N = 2500 is past the kernel's station cache and takes the rescan).  The
+    gradient sums must match autograd of the oracle term by term."""
+    gen = torch.Generator().manual_seed(N)
+    B, T, H, W, s = 2, 2, 6, 5, 2
+    pred = torch.randn(B, T, 1, H * s, W * s, generator=gen) * 3
+    lr = torch.rand(B, T, 1, H, W, generator=gen) * 5
+    coords = torch.stack([torch.randint(0, H + 1, (N,), generator=gen), torch.randint(0, W, (N,), generator=gen)], 1)
+    values = torch.rand(B, T, N, generator=gen) * 30
+    values[torch.rand(B, T, N, generator=gen) < 0.1] = float("nan")
+    _, p, total, parts = _run_fused(gpu, pred, lr, coords, values, float(s))
+    po, to, parts_o = _oracle(pred, lr, coords, values, float(s), [1.0, 1.0, 0.1, 0.05], True, "log")
+    for k in parts_o:
+        assert _close(float(parts[k]), float(parts_o[k]), rel=1e-4), (k, float(parts[k]), float(parts_o[k]))
+    total.backward()
+    to.backward()
+    err = (p.grad.cpu() - po.grad).abs().max().item()
+    assert err <= 2e-5 * po.grad.abs().max().item() + 1e-9, err       # sums of up to ~100 terms per pixel
