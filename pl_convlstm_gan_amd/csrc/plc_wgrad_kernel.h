@@ -79,8 +79,16 @@ struct WgradGeom {
     static constexpr int NPF = (IN_UNITS + DZ_UNITS + 511) / 512;
 };
 
+// Waves per SIMD to compile for: the instantiations whose LDS double buffer lets two workgroups share a
+// CU are launched that way (2 x 8 waves = 4 per SIMD), so they must stay within 128 VGPRs; one register
+// more and only one workgroup is resident while the host still launches two per CU (cell 1: 137 -> 172 us).
+template <int NCB, int MT, int KS>
+constexpr int plc_wgrad_min_waves() {
+    return WgradGeom<NCB, MT, KS>::LDS_BYTES <= 80 * 1024 ? 4 : 2;
+}
+
 template <int NCB0, int NCB1, int MT, int KS, int STAGE>
-__global__ __launch_bounds__(512, 2) void plc_wgrad_kernel(const WgradArgs a) {
+__global__ __launch_bounds__(512, (plc_wgrad_min_waves<NCB0 + NCB1, MT, KS>())) void plc_wgrad_kernel(const WgradArgs a) {
     using G = WgradGeom<NCB0 + NCB1, MT, KS>;
     constexpr int NCB = NCB0 + NCB1;
     static_assert(MT == 1 || MT == 2 || MT == 4, "MT must be 1, 2 or 4");
