@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Benchmark of the ConvLSTM rollout hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--mode train|fwd] [--config c3|c2|c1|c4|c5|p2]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--mode train|fwd] [--config c3|c2|c1|c4|c5|p2|c0]
                     [--global-batch G]
 
 With --gpus N > 1 and no torchrun environment the script starts the N ranks itself (one process per
@@ -42,6 +42,7 @@ CONFIGS = {
     "c4": (4, 20, 256, 256, 1),    # configs[3] per-GPU shard (generator only)
     "c5": (1, 10, 512, 512, 1),    # configs[4] per-GPU shard; its gate convs default to the fp8 (e4m3) path
     "p2": (4, 10, 32, 32, 8),      # default.yaml-faithful x8 downscaling to 256x256
+    "c0": (8, 5, 15, 12, 8),       # the reference's own shape: default.yaml (batch 8, T=5, x8) on its 15x12 basin grid -> 120x96
 }
 FLOP_PER_PX_FWD = 171104          # algorithmic forward FLOPs per output pixel per frame (scale 1, L=5)
 FWD_BYTES_PER_PX = 804            # algorithmic forward tensor traffic per pixel per frame: 402 elements as bf16

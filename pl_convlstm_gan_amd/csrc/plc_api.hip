@@ -364,51 +364,27 @@ static int launch_cell(const ConvArgs& a, int B, int Cin, int Ch, hipStream_t st
 // The cells' tensors are described once, with the byte stride of one time step as the outer stride of
 // every PlcTensor: image index t * B + b then addresses step t, and since tiles are numbered
 // image-major a workgroup reaches step t of its own tile by adding t * (tiles of one step) to its
-// tile number.  The descriptors stay in the kernel arguments untouched (copies adjusted per phase
-// cost more scalar registers than the cell kernels have to spare).
+// tile number -- which is exactly the tile loop of plc_conv_body in its PERSIST mode.
 struct PersistArgs {
-    ConvArgs c1z, c1, c2z, c2;  // cell 1 / cell 2; the z variants are step 0 (zero initial state: h, c not read)
-    int T, n1, n2;              // steps; tiles (= workgroups) of one step of cell 1 / cell 2
-    unsigned* counter;          // zero at launch
+    ConvArgs c1, c2;            // cell 1 / cell 2 with zero_state = 1 (it applies to the first step only)
+    int n1;                     // tiles (= workgroups) of one step of cell 1; the rest of the grid is cell 2
 };
 
-__device__ __forceinline__ void plc_grid_barrier(unsigned* counter, unsigned target) {
-    __syncthreads();                               // this workgroup's stores have been issued and counted
-    if (threadIdx.x == 0) {
-        __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        while (__hip_atomic_load(counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target)
-            __builtin_amdgcn_s_sleep(2);
-    }
-    __syncthreads();
-}
-
 template <int TH, bool SAVE>
-__global__ __launch_bounds__(256, (TH == 8 ? 1 : 2)) void plc_lstm_persistent_kernel(const PersistArgs p) {
+__global__ __launch_bounds__(256, 1) void plc_lstm_persistent_kernel(const PersistArgs p) {
     extern __shared__ __attribute__((aligned(16))) uint4 plc_persist_tile[];
     constexpr int EPI = SAVE ? EPI_LSTM_SAVE : EPI_LSTM;
-    if ((int)blockIdx.x < p.n1) {
-#pragma unroll 1
-        for (int phase = 0; phase <= p.T; ++phase) {
-            if (phase < p.T)
-                plc_conv_body<2, 2, 2, 3, STAGE_CB8, EPI, TH>(phase == 0 ? p.c1z : p.c1, blockIdx.x + phase * p.n1, 0, 1,
-                                                              plc_persist_tile);
-            if (phase < p.T) plc_grid_barrier(p.counter, (unsigned)(phase + 1) * gridDim.x);
-        }
-    } else {
-#pragma unroll 1
-        for (int phase = 0; phase <= p.T; ++phase) {
-            if (phase >= 1)
-                plc_conv_body<2, 4, 4, 3, STAGE_CB8, EPI, TH>(phase == 1 ? p.c2z : p.c2,
-                                                              (blockIdx.x - p.n1) + (phase - 1) * p.n2, 0, 1, plc_persist_tile);
-            if (phase < p.T) plc_grid_barrier(p.counter, (unsigned)(phase + 1) * gridDim.x);
-        }
-    }
+    // each branch keeps its cell's weights in registers for the whole rollout
+    if ((int)blockIdx.x < p.n1)
+        plc_conv_body<2, 2, 2, 3, STAGE_CB8, EPI, TH, 1, 1>(p.c1, blockIdx.x, 0, 1, plc_persist_tile);
+    else
+        plc_conv_body<2, 4, 4, 3, STAGE_CB8, EPI, TH, 1, 2>(p.c2, blockIdx.x - p.n1, 0, 1, plc_persist_tile);
 }
 
 // Launches the recurrence as one persistent kernel when both cells' tiles fit the chip at once (and
 // the widths are the instantiated [16,32]); *done tells the caller whether it did.
 template <int TH, bool SAVE>
-static int launch_persistent_th(PersistArgs p, int n_img, hipStream_t st, bool* done) {
+static int launch_persistent_th(PersistArgs p, int n_img, int T, hipStream_t st, bool* done) {
     constexpr int lds1 = plc_conv_lds_bytes<4, 3, TH, 1, STAGE_CB8>(), lds2 = plc_conv_lds_bytes<6, 3, TH, 1, STAGE_CB8>();
     constexpr int lds = lds1 > lds2 ? lds1 : lds2;
     auto kern = plc_lstm_persistent_kernel<TH, SAVE>;
@@ -417,37 +393,34 @@ static int launch_persistent_th(PersistArgs p, int n_img, hipStream_t st, bool* 
         int rc = ensure_lds_limit((const void*)kern, lds, lds_raised);
         if (rc) return rc;
     }
-    for (ConvArgs* a : {&p.c1z, &p.c1, &p.c2z, &p.c2}) {
+    for (ConvArgs* a : {&p.c1, &p.c2}) {
         a->tiles_x = cdiv(a->W, 32);
         a->tiles_y = cdiv(a->H, TH);
         const long long per_step = (long long)n_img * a->tiles_x * a->tiles_y;
-        if (per_step * p.T >= (1ll << 31)) return PLC_OK;
-        a->n_tiles = (int)(per_step * p.T);          // tile numbers run over all steps
-        a->n_blocks = a->n_tiles;
+        if (per_step * T >= (1ll << 31)) return PLC_OK;
+        a->n_blocks = (int)per_step;                 // the tile loop's stride: the same tile, one step on
+        a->n_tiles = (int)(per_step * T);            // tile numbers run over all steps
     }
-    p.n1 = p.c1.n_tiles / p.T;
-    p.n2 = p.c2.n_tiles / p.T;
-    const int grid = p.n1 + p.n2;
+    p.n1 = p.c1.n_blocks;
+    const int grid = p.c1.n_blocks + p.c2.n_blocks;
     int per_cu = 0;
     PLC_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)kern, 256, lds));
     // Only grids that take at most a quarter of the chip's workgroup slots: the whole grid must be
     // resident for the barrier to complete, and a second process (or stream) doing the same on this GPU
     // must still find room for ITS whole grid.  Larger grids have launches long enough not to need this.
     if (per_cu <= 0 || grid > per_cu * cu_count() / 4) return PLC_OK;
-    PLC_HIP(hipMemsetAsync(p.counter, 0, sizeof(unsigned), st));
+    PLC_HIP(hipMemsetAsync(p.c1.sync, 0, sizeof(unsigned), st));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, p);
     PLC_HIP(hipGetLastError());
     *done = true;
     return PLC_OK;
 }
 
-static int launch_persistent(const PersistArgs& p, int n_img, bool save, hipStream_t st, bool* done) {
+// 8-row tiles: the grids this path accepts are small (see the residency rule above), so the finer tiling
+// is what spreads them over the chip.
+static int launch_persistent(const PersistArgs& p, int n_img, int T, bool save, hipStream_t st, bool* done) {
     *done = false;
-    const long long t16 = (long long)n_img * cdiv(p.c1.H, 16) * cdiv(p.c1.W, 32);
-    // 16-row tiles when they still give every CU a workgroup of each cell, else 8-row tiles
-    if (t16 >= cu_count())
-        return save ? launch_persistent_th<16, true>(p, n_img, st, done) : launch_persistent_th<16, false>(p, n_img, st, done);
-    return save ? launch_persistent_th<8, true>(p, n_img, st, done) : launch_persistent_th<8, false>(p, n_img, st, done);
+    return save ? launch_persistent_th<8, true>(p, n_img, T, st, done) : launch_persistent_th<8, false>(p, n_img, T, st, done);
 }
 
 static int cell_fwd_cb8(const void* x, const void* h, const float* c_in, const void* wpk, const float* bpk,
@@ -956,14 +929,10 @@ extern "C" int plc_generator_rollout_fwd(const plc_rollout_desc* d, void* stream
                 a.out2.so = 4 * s_h;
                 return a;
             };
-            pa.c1z = stepped(cell1(0), (long long)s1, (long long)s1);
-            pa.c2z = stepped(cell2(0), (long long)s1, (long long)s2);
-            pa.c1 = pa.c1z;
-            pa.c2 = pa.c2z;
-            pa.c1.zero_state = pa.c2.zero_state = 0;
-            pa.T = T;
-            pa.counter = (unsigned*)(ws + p.sync);
-            if ((rc = launch_persistent(pa, B, save, st, &persistent))) return rc;
+            pa.c1 = stepped(cell1(0), (long long)s1, (long long)s1);
+            pa.c2 = stepped(cell2(0), (long long)s1, (long long)s2);
+            pa.c1.sync = pa.c2.sync = (unsigned*)(ws + p.sync);
+            if ((rc = launch_persistent(pa, B, T, save, st, &persistent))) return rc;
         }
         if (!persistent)
             for (int t = 0; t < T; ++t) {

@@ -71,6 +71,7 @@ struct ConvArgs {
     int mul_mode;        // EPI_ACT_CB8 with `mul`: MUL_PRODUCT (v *= m) or MUL_RELU_MASK (v = m > 0 ? v : 0)
     int g_ncb0, g_ncb1;  // run-time-width kernel (plc_convg_kernel.h) only: channel blocks of src0 / src1
     int g_nmt;           // ... and the conv's 32-row output tiles
+    unsigned* sync;      // persistent recurrence (PERSIST != 0): the device-wide barrier's counter, zero at launch
     PlcTensor src0;      // CB8 bf16, first NCB0 channel blocks   (STAGE_COORD / STAGE_F32_1CH: fp32 plane)
     PlcTensor src1;      // CB8 bf16, next NCB1 channel blocks
     PlcTensor gate;      // STAGE_CB8_GATED: CB8 bf16 multiplier of src0
@@ -351,6 +352,21 @@ __device__ __forceinline__ void plc_lds_barrier() {
     asm volatile("" ::: "memory");
 }
 
+// Device-wide barrier of a grid that is resident all at once: arrive with a release at agent scope (this
+// workgroup's stores leave the XCD's L2), poll the counter with relaxed device-coherent loads, then one
+// acquire fence (stale lines are dropped once, not on every poll).  `target` = arrivals that complete
+// this barrier; the counter only grows, so barrier k of a launch uses (k + 1) * gridDim.x.
+__device__ __forceinline__ void plc_grid_barrier(unsigned* counter, unsigned target) {
+    __syncthreads();                               // this workgroup's stores have been issued and counted
+    if (threadIdx.x == 0) {
+        __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target)
+            __builtin_amdgcn_s_sleep(1);
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    }
+    __syncthreads();
+}
+
 // s_waitcnt vmcnt(n) for a wave-uniform run-time n (the instruction takes an immediate): waits until
 // at most n of this wave's vector-memory operations are outstanding.  Values above the table wait
 // for a smaller count, which is only stricter.
@@ -412,7 +428,8 @@ constexpr bool plc_conv_multi_tile() {
 // groups reads are requested first; the return value is the number of later pieces this wave issued
 // (loads retire in order, so "all but the n_late youngest" is exactly the early set).
 template <int NCB0, int NCB1, int KS, int TH, int STAGE, bool SPLIT, int RG, int RPW, int NREP, int TILE_UNITS, int GATE_OFF>
-__device__ __forceinline__ int plc_dma_issue(const ConvArgs& a, uint4* tile, int lane, int wave_u, int n, int x0, int y0) {
+__device__ __forceinline__ int plc_dma_issue(const ConvArgs& a, uint4* tile, int lane, int wave_u, int n, int x0, int y0,
+                                             int zero_state) {
     constexpr int NCB = NCB0 + NCB1, PAD = KS / 2, LH = TH + 2 * PAD, LW = 32 + 2 * PAD, PLANE = LH * LW;
     constexpr int NCHUNK = TILE_UNITS / 64;
     const int H = a.H, W = a.W;
@@ -439,7 +456,7 @@ __device__ __forceinline__ int plc_dma_issue(const ConvArgs& a, uint4* tile, int
             const int ly = r / LW;
             const int lx = r - ly * LW;
             const int gy = y0 - PAD + ly, gx = x0 - PAD + lx;
-            const bool ok = (cb < NCB) & (gy >= 0) & (gy < H) & (gx >= 0) & (gx < W) & !(a.zero_state && cb >= NCB0);
+            const bool ok = (cb < NCB) & (gy >= 0) & (gy < H) & (gx >= 0) & (gx < W) & !(zero_state && cb >= NCB0);
             const char* base = (cb < NCB0) ? (s0 + cb * plane_b) : (s1 + (cb - NCB0) * plane_b);
             const long long poff = cb * plane_b + ((long long)gy * W + gx) * 16;
             const char* src = ok ? base + ((long long)gy * W + gx) * 16 : (const char*)&plc_zero16;
@@ -466,7 +483,12 @@ __device__ __forceinline__ void plc_decode_tile(const ConvArgs& a, int th, int i
 
 // The work of one workgroup: tile `block_x` (image-major, then tile row, then tile column) of M
 // group `block_y` of `n_mgroups`; `tile` is the workgroup's dynamic LDS.
-template <int NCB0, int NCB1, int NMT, int KS, int STAGE, int EPI, int TH, int KSPLIT = 1>
+// PERSIST (ConvLSTM cells only): the workgroup keeps its weights and walks the SAME spatial tile through
+// all time steps (tile numbers run over the steps: block_x, block_x + n_blocks, ...; the tensors' outer
+// stride is one step), meeting every other workgroup of the grid at a device-wide barrier between
+// steps: PERSIST == 1 (cell 1) arrives AFTER each step, PERSIST == 2 (cell 2) BEFORE each step, so cell 2
+// of step t runs beside cell 1 of step t + 1.  a.zero_state then applies to the first step only.
+template <int NCB0, int NCB1, int NMT, int KS, int STAGE, int EPI, int TH, int KSPLIT = 1, int PERSIST = 0>
 __device__ __forceinline__ void plc_conv_body(const ConvArgs& a, const int block_x, const int block_y,
                                               const int n_mgroups, uint4* const tile) {
     constexpr int NCB = NCB0 + NCB1;
@@ -564,12 +586,14 @@ __device__ __forceinline__ void plc_conv_body(const ConvArgs& a, const int block
     // on lambdas of this shape in the multi-tile instantiations)
 #define PLC_DMA_ISSUE(n_, x0_, y0_)                                                                     \
     plc_dma_issue<NCB0, NCB1, KS, TH, STAGE, SPLIT_STAGE, RG, RPW, NREP, TILE_UNITS,                    \
-                  TILE_UNITS + RED_UNITS + BIAS_UNITS>(a, tile, lane, wave_u, n_, x0_, y0_)
+                  TILE_UNITS + RED_UNITS + BIAS_UNITS>(a, tile, lane, wave_u, n_, x0_, y0_, zs)
     // Multi-tile workgroups request tile k+1 as soon as every wave has finished READING tile k (after
     // the last pass's MFMA loop), so the transfer runs under that pass's stores: the epilogue does
     // not touch the LDS tile.  (Timeline of the gated post conv before: 3.4 us tile wait, 0.9 us
     // MFMAs, 1.4 us stores per tile.)  The first tile is requested here.
     constexpr bool PREFETCH = plc_conv_multi_tile<STAGE, EPI>();
+    static_assert(PERSIST == 0 || (IS_LSTM && !PREFETCH), "PERSIST is for the ConvLSTM cells");
+    int zs = a.zero_state;      // (PERSIST: cleared after the first step)
     if constexpr (PREFETCH) {
         int n_, x0_, y0_;
         plc_decode_tile(a, TH, block_x, n_, x0_, y0_);
@@ -590,6 +614,11 @@ __device__ __forceinline__ void plc_conv_body(const ConvArgs& a, const int block
     } while (0)
 #pragma unroll 1
     for (int tile_id = block_x; tile_id < a.n_tiles; tile_id += a.n_blocks) {
+    if constexpr (PERSIST != 0) {
+        const int step = (tile_id - block_x) / a.n_blocks;
+        zs = step == 0 ? a.zero_state : 0;
+        if constexpr (PERSIST == 2) plc_grid_barrier(a.sync, (unsigned)(step + 1) * gridDim.x);
+    }
     int n, x0, y0;
     plc_decode_tile(a, TH, tile_id, n, x0, y0);
 
@@ -807,7 +836,7 @@ __device__ __forceinline__ void plc_conv_body(const ConvArgs& a, const int block
 #pragma unroll
                     for (int r = 0; r < NREP; ++r)   // the POINTER is selected, so the load is unconditional and
                                                      // nothing waits for it before its first use one pass later
-                        cnew[r] = plc_gload_f4(a.zero_state ? (const char*)&plc_zero16
+                        cnew[r] = plc_gload_f4(zs ? (const char*)&plc_zero16
                                                             : cin_base + (long long)(y0 + row0 + r) * W * 32 + lane_c);
                     bf16x8_t fr[NF];
                     const char* fbase = lds + row0 * LW * 16 + (px * 16 + half * PLANE * 16);
@@ -891,7 +920,8 @@ __device__ __forceinline__ void plc_conv_body(const ConvArgs& a, const int block
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             PLC_STAMP(7);
 #endif
-            return;   // (the LSTM convs take one tile per workgroup)
+            if constexpr (PERSIST != 0) goto tile_done;
+            else return;   // (the LSTM convs take one tile per workgroup)
         }
     }
 
@@ -913,7 +943,7 @@ __device__ __forceinline__ void plc_conv_body(const ConvArgs& a, const int block
             cpre[r] = make_float4(0.f, 0.f, 0.f, 0.f);
             if constexpr (IS_LSTM) {
                 const int gy = y0 + row0 + r, gx = x0 + px;
-                if (gy < H && gx < W && !a.zero_state)
+                if (gy < H && gx < W && !zs)
                     cpre[r] = *(const float4*)(plc_img(a.c_in, n, a.n_in) +
                                                ((long long)mt * H * W + (long long)gy * W + gx) * 32 + half * 16);
             }
@@ -1040,7 +1070,9 @@ __device__ __forceinline__ void plc_conv_body(const ConvArgs& a, const int block
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     PLC_STAMP(7);
 #endif
-    if constexpr (!plc_conv_multi_tile<STAGE, EPI>()) break;
+tile_done:
+    if constexpr (PERSIST == 1) plc_grid_barrier(a.sync, (unsigned)((tile_id - block_x) / a.n_blocks + 1) * gridDim.x);
+    if constexpr (!plc_conv_multi_tile<STAGE, EPI>() && PERSIST == 0) break;
     }   // tile loop
 #undef PLC_PREFETCH_NEXT
 #undef PLC_DMA_ISSUE
