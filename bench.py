@@ -232,6 +232,9 @@ def main():
                     "32,64 is the reference's class default and runs on the run-time-width kernels)")
     ap.add_argument("--gate-dtype", default=None, choices=["bf16", "fp8"],
                     help="operand type of the two gate convs (default: fp8 for c5, BASELINE configs[4]; bf16 otherwise)")
+    ap.add_argument("--graph", action="store_true",
+                    help="train mode, one GPU: capture the step into a HIP graph and replay it (pays on launch-bound "
+                         "shapes such as c0 / p2 / c1; the large configs are GPU-bound either way)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
     if args.gpus < 1:
@@ -297,9 +300,18 @@ def main():
     opt = FusedAdam(model.parameters(), lr=5e-4)   # torch.optim.Adam's rule; clip + step in two launches
     dbg("model and data ready")
 
+    graphed = None
+    if args.graph:
+        if world > 1 or args.mode != "train":
+            raise SystemExit("bench.py: --graph is for --mode train on one GPU")
+        from pl_convlstm_gan_amd.training import GraphedTrainStep
+        graphed = GraphedTrainStep(model, loss_module, opt, (rain, dem, lu, coords, values), max_norm=0.5)
+
     def step_train():
         # nan_check="device": the reference's NaN-batch skip is carried out by the optimizer kernel
         # (no host synchronisation inside the step), as the Trainer runs it
+        if graphed is not None:
+            return graphed(rain, dem, lu, coords, values)[0]
         return train_step(model, loss_module, opt, rain, dem, lu, coords, values, max_norm=0.5, nan_check="device")[0]
 
     def step_fwd():
@@ -350,7 +362,7 @@ def main():
             "config": {"workload": f"{args.config}: {what}, B={B}/GPU, T={T}, {H}x{W} -> {H * s}x{W * s}, 1 channel, "
                                    f"hidden [{args.hidden}], L=5, scale_factor={s}, {N_STATIONS} stations, gate convs {gate_dtype}"
                                    + (" (e4m3 operands, fp32 accumulate; every other conv and the backward pass bf16)" if gate_dtype == "fp8" else ""),
-                       "global_batch": world * B, "T": T, "mode": args.mode,
+                       "global_batch": world * B, "T": T, "mode": args.mode + (" (HIP-graph replay)" if args.graph else ""),
                        "parallelism": f"dp{world} (batch sharded; one flat-gradient all-reduce per step)"},
             "fwd_frames_per_s": world * B * T * n_fwd / dt_fwd,
         }

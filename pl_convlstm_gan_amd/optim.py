@@ -47,6 +47,39 @@ class FusedAdam(torch.optim.Optimizer):
         self.sync_steps()
         return super().state_dict()
 
+    # ---- support for a captured (HIP graph) step: the state tensors must keep their addresses -----------
+    def snapshot(self):
+        """Copies of every state tensor, keyed by parameter identity."""
+        self.sync_steps()
+        return {id(p): {k: v.clone() for k, v in st.items() if torch.is_tensor(v)} for p, st in self.state.items()}
+
+    @torch.no_grad()
+    def restore_(self, snap):
+        """Put the state back IN PLACE (state created since the snapshot is zeroed): a captured graph keeps
+        pointing at these tensors."""
+        self.sync_steps()
+        for p, st in self.state.items():
+            old = snap.get(id(p), {})
+            for k, v in st.items():
+                if torch.is_tensor(v):
+                    if k in old:
+                        v.copy_(old[k])
+                    else:
+                        v.zero_()
+        if self._dev_step is not None and self._dev_params:
+            self._dev_step.fill_(int(float(self.state[self._dev_params[0]]["step"])))
+        self._unsynced = False
+
+    def uncount_captured_step(self):
+        """A guarded step issued under graph capture advanced the host-side ``step`` entries but ran
+        nothing: take the advance back (the device counter is what the replays move)."""
+        for p in self._dev_params:
+            self.state[p]["step"] -= 1
+
+    def note_replayed_step(self):
+        """A replay advanced the device counter: the host-side entries are behind until sync_steps()."""
+        self._unsynced = True
+
     def load_state_dict(self, state_dict):
         super().load_state_dict(state_dict)
         self._dev_step, self._dev_params, self._unsynced = None, [], False

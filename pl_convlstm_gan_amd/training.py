@@ -174,3 +174,76 @@ def train_step(model, loss_module, optimizer, rain_lr, dem, lu, s_coords, s_valu
             else torch.isnan(guard).reshape(())
         return loss, loss_dict, fake_hr, skipped
     return loss, loss_dict, fake_hr, False
+
+
+class GraphedTrainStep:
+    """``train_step(..., nan_check="device")`` captured once into a HIP graph and replayed.
+
+    For shapes where a step is launch-bound (the reference's own 15x12 basin grid: ~100 kernels of a few
+    microseconds each) the replay removes the host work of a step -- descriptor building, ~100 launches,
+    PyTorch's autograd bookkeeping -- and the gaps between the kernels.  Every library call is plain
+    stream work without allocation or synchronisation, and the NaN-batch skip is decided on the device,
+    so the whole step (zero_grad, forward, CombinedLoss, BPTT, clip, Adam) captures as it is.
+
+    * one instance serves ONE batch shape; inputs are copied into the capture's static buffers;
+    * the returned tensors (loss, loss parts, prediction, skipped flag) live in the graph's memory pool
+      and are overwritten by the next replay: read or clone them before stepping again;
+    * the learning rate is a launch argument, so a changed ``param_groups[0]['lr']`` (ReduceLROnPlateau)
+      triggers a re-capture; the Adam step count lives on the device and advances with every replay;
+    * building the instance runs ``warmup`` real steps on the example batch (lazy upsample blocks,
+      workspaces, optimizer state are created outside the capture) and then restores parameters and
+      optimizer state in place, so the first replay starts from the state the caller handed in;
+    * single process only (a captured RCCL all-reduce has not been exercised here: data-parallel
+      runs use the eager step).
+    """
+
+    def __init__(self, model, loss_module, optimizer, example_batch, *, max_norm: float = 0.5,
+                 forward_kwargs: Optional[dict] = None, clip_params: Optional[Iterable] = None, warmup: int = 2):
+        if not hasattr(optimizer, "clip_and_step"):
+            raise TypeError("GraphedTrainStep needs optim.FusedAdam (the NaN-batch skip must run on the device)")
+        if _world() > 1:
+            raise RuntimeError("GraphedTrainStep is single-process: use train_step under data parallelism")
+        self.model, self.loss_module, self.optimizer = model, loss_module, optimizer
+        self.max_norm, self.forward_kwargs = max_norm, forward_kwargs
+        self.clip_params = list(clip_params) if clip_params is not None else None
+        self.static = [t.detach().clone() for t in example_batch]
+        if not all(t.is_cuda for t in self.static):
+            raise RuntimeError("GraphedTrainStep: the batch must be on the GPU")
+        params = [p.detach().clone() for p in model.parameters()]
+        had_state = optimizer.snapshot()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(max(1, warmup)):
+                self._eager()
+        torch.cuda.current_stream().wait_stream(side)
+        with torch.no_grad():
+            for p, s in zip(model.parameters(), params):      # (the lazy blocks created by the warm-up keep their values)
+                p.copy_(s)
+        optimizer.restore_(had_state)
+        self.graph = None
+        self._capture()
+
+    def _eager(self):
+        return train_step(self.model, self.loss_module, self.optimizer, *self.static, max_norm=self.max_norm,
+                          forward_kwargs=self.forward_kwargs, clip_params=self.clip_params, nan_check="device")
+
+    def _capture(self):
+        self.lr = float(self.optimizer.param_groups[0]["lr"])
+        self.optimizer.sync_steps()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.out = self._eager()
+        # the capture queued nothing; undo the host-side step bookkeeping it did
+        self.optimizer.uncount_captured_step()
+
+    def __call__(self, rain_lr, dem, lu, s_coords, s_values):
+        for dst, src in zip(self.static, (rain_lr, dem, lu, s_coords, s_values)):
+            if dst.shape != src.shape:
+                raise ValueError(f"GraphedTrainStep was captured for shape {tuple(dst.shape)}, got {tuple(src.shape)}")
+            dst.copy_(src, non_blocking=True)
+        if float(self.optimizer.param_groups[0]["lr"]) != self.lr:
+            self._capture()
+        self.graph.replay()
+        self.optimizer.note_replayed_step()
+        return self.out

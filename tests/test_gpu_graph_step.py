@@ -1,0 +1,61 @@
+"""The training step captured into a HIP graph (training.GraphedTrainStep) against the eager step: the
+same kernels replayed, so parameters, losses and the NaN-batch skip must agree bit for bit over several
+steps on different batches -- including a batch whose loss is NaN (skipped on the device) and a change of
+the learning rate between steps (re-capture)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _batch(seed, dev, nan=False, B=4, T=3, H=15, W=12, s=2, N=6):
+    g = torch.Generator().manual_seed(seed)
+    rain = 10 * torch.rand(B, T, 1, H, W, generator=g)
+    dem = torch.rand(B, 1, H * s, W * s, generator=g)
+    lu = torch.rand(B, 5, H * s, W * s, generator=g)
+    coords = torch.randint(0, min(H, W), (N, 2), generator=g).unsqueeze(0).repeat(B, 1, 1)
+    values = 20 * torch.rand(B, T, N, generator=g)
+    if nan:
+        values = values - 100.0          # log1p(< -1) -> NaN loss (reference behaviour)
+    return [t.to(dev) for t in (rain, dem, lu, coords, values)]
+
+
+def _setup(gpu):
+    from pl_convlstm_gan_amd import Generator
+    from pl_convlstm_gan_amd.losses import CombinedLoss
+    from pl_convlstm_gan_amd.optim import FusedAdam
+    torch.manual_seed(0)
+    model = Generator(hidden_dims=[16, 32], lu_channels=5, scale_factor=2).to(gpu)
+    with torch.no_grad():
+        model(*_batch(1, gpu)[:3])           # the lazy block exists before either run starts (same RNG draw)
+    return model, CombinedLoss(), FusedAdam(model.parameters(), lr=5e-4)
+
+
+def test_graphed_step_equals_eager_step(gpu):
+    from pl_convlstm_gan_amd.training import GraphedTrainStep, train_step
+    plan = [(10, False, 5e-4), (20, True, 5e-4), (30, False, 5e-4), (40, False, 2e-4), (50, False, 2e-4)]
+
+    model, loss_mod, opt = _setup(gpu)
+    eager = []
+    for seed, nan, lr in plan:
+        opt.param_groups[0]["lr"] = lr
+        loss, parts, _, skipped = train_step(model, loss_mod, opt, *_batch(seed, gpu, nan), max_norm=0.5, nan_check="device")
+        eager.append((float(loss.detach()), bool(skipped), torch.cat([p.detach().reshape(-1) for p in model.parameters()]).clone()))
+    steps_eager = opt.state_dict()["state"][0]["step"]
+
+    model, loss_mod, opt = _setup(gpu)
+    start = torch.cat([p.detach().reshape(-1) for p in model.parameters()]).clone()
+    step = GraphedTrainStep(model, loss_mod, opt, _batch(99, gpu), max_norm=0.5)
+    assert torch.equal(torch.cat([p.detach().reshape(-1) for p in model.parameters()]), start)    # warm-up left no trace
+    for (seed, nan, lr), (l_ref, s_ref, p_ref) in zip(plan, eager):
+        opt.param_groups[0]["lr"] = lr
+        loss, parts, pred, skipped = step(*_batch(seed, gpu, nan))
+        got = float(loss.detach())
+        assert (got != got and l_ref != l_ref) or got == l_ref
+        assert bool(skipped) == s_ref
+        assert torch.equal(torch.cat([p.detach().reshape(-1) for p in model.parameters()]), p_ref)
+    assert [s for _, s, _ in eager] == [False, True, False, False, False]
+    # the Adam step count lives on the device: 4 applied updates, as in the eager run
+    assert float(opt.state_dict()["state"][0]["step"]) == float(steps_eager) == 4.0
+    with pytest.raises(ValueError, match="captured for shape"):
+        step(*_batch(60, gpu, B=2))
