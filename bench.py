@@ -384,13 +384,17 @@ def main():
         if os.path.exists(tj) and args.config == "c3":
             traffic = json.load(open(tj)).get("hbm_bytes_per_launch")
         peak = PEAK_FP8 if fp8 else PEAK_BF16
+        fp8_traffic = None
+        fj = os.path.join(ROOT, "profiles", "r2_cell2_fp8_traffic.json")
+        if fp8 and os.path.exists(fj) and args.config == "c5":
+            fp8_traffic = json.load(open(fj)).get("hbm_bytes_per_launch")
         # fp8 operands: x 16 + h 32 bytes per pixel read (instead of 32 + 64), h' written twice (bf16 64 + fp8 32)
         cell_bytes = (CELL2_BYTES_PER_PX - 48 + 32) if fp8 else CELL2_BYTES_PER_PX
         mfma_roof = {"bound": "mfma",
                      "kernel": ("plc_lstm_fp8_kernel<1,2,4> (cell-2 gate conv, e4m3 on v_mfma_scale_f32_32x32x64_f8f6f4, + LSTM epilogue)"
                                 if fp8 else "plc_conv_mfma_kernel<2,4,4,3,CB8,LSTM> (cell-2 gate conv + LSTM epilogue)"),
                      "achieved": flops / tk / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s",
-                     "frac": flops / tk / peak, "traffic": None if fp8 else traffic,
+                     "frac": flops / tk / peak, "traffic": fp8_traffic if fp8 else traffic,
                      "launch_us": tk * 1e6, "flop_per_launch": flops,
                      "alg_bytes_per_launch": cell_bytes * B * H * W,
                      "hbm_frac": cell_bytes * B * H * W / tk / PEAK_HBM}
