@@ -334,6 +334,12 @@ static bool plc_no_persistent() {
     return e && e[0] && e[0] != '0';
 }
 
+// PLC_NO_PAIRING=1 keeps cell 1 and cell 2 in launches of their own (A/B timing, tests).
+static bool plc_no_pairing() {
+    const char* e = getenv("PLC_NO_PAIRING");
+    return e && e[0] && e[0] != '0';
+}
+
 // One ConvLSTM cell launch; a.save_gates selects the variant that stores i,f,o,g for the backward pass.
 static int launch_cell(const ConvArgs& a, int B, int Cin, int Ch, hipStream_t st) {
     const bool gates = a.save_gates != 0;
@@ -421,6 +427,63 @@ static int launch_persistent_th(PersistArgs p, int n_img, int T, hipStream_t st,
 static int launch_persistent(const PersistArgs& p, int n_img, int T, bool save, hipStream_t st, bool* done) {
     *done = false;
     return save ? launch_persistent_th<8, true>(p, n_img, T, st, done) : launch_persistent_th<8, false>(p, n_img, T, st, done);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Cell 2 of step t and cell 1 of step t + 1 in one launch (they do not depend on each other: both read
+// h1 of step t).  The workgroups of cell 2 come FIRST in the grid and fill the chip; as they retire the
+// workgroups of cell 1 take their places, so cell 1's weight and halo-tile fetches run under the tail of
+// cell 2's arithmetic instead of on an idle chip, and the next launch's cell 2 does the same under the
+// tail of cell 1.  (Interleaving the two kinds so that every CU starts with one of each made them run
+// in lockstep and gained nothing; the order is what staggers them.)
+// ---------------------------------------------------------------------------------------------
+struct PairArgs {
+    ConvArgs c2, c1;
+    int n2;                     // workgroups (= tiles) of cell 2; the rest of the grid is cell 1
+};
+
+template <int TH, bool SAVE>
+__global__ __launch_bounds__(256, 2) void plc_lstm_pair_kernel(const PairArgs p) {
+    extern __shared__ __attribute__((aligned(16))) uint4 plc_pair_tile[];
+    constexpr int EPI = SAVE ? EPI_LSTM_SAVE : EPI_LSTM;
+    if ((int)blockIdx.x < p.n2)
+        plc_conv_body<2, 4, 4, 3, STAGE_CB8, EPI, TH>(p.c2, blockIdx.x, 0, 1, plc_pair_tile);
+    else
+        plc_conv_body<2, 2, 2, 3, STAGE_CB8, EPI, TH>(p.c1, blockIdx.x - p.n2, 0, 1, plc_pair_tile);
+}
+
+template <int TH, bool SAVE>
+static int launch_pair_th(PairArgs p, int n_img, hipStream_t st) {
+    constexpr int lds1 = plc_conv_lds_bytes<4, 3, TH, 1, STAGE_CB8>(), lds2 = plc_conv_lds_bytes<6, 3, TH, 1, STAGE_CB8>();
+    constexpr int lds = lds1 > lds2 ? lds1 : lds2;
+    auto kern = plc_lstm_pair_kernel<TH, SAVE>;
+    if (lds > 65536) {
+        static bool lds_raised[64] = {false};
+        int rc = ensure_lds_limit((const void*)kern, lds, lds_raised);
+        if (rc) return rc;
+    }
+    for (ConvArgs* a : {&p.c2, &p.c1}) {
+        a->tiles_x = cdiv(a->W, 32);
+        a->tiles_y = cdiv(a->H, TH);
+        a->n_tiles = n_img * a->tiles_x * a->tiles_y;
+        a->n_blocks = a->n_tiles;
+    }
+    p.n2 = p.c2.n_tiles;
+    hipLaunchKernelGGL(kern, dim3(p.c2.n_tiles + p.c1.n_tiles), dim3(256), lds, st, p);
+    PLC_HIP(hipGetLastError());
+    return PLC_OK;
+}
+
+// widths [16,32] only; the tile height follows launch_conv's rule so that results equal the single launches'
+static int launch_pair(const ConvArgs& c2, const ConvArgs& c1, int n_img, hipStream_t st) {
+    PairArgs p;
+    memset(&p, 0, sizeof(p));
+    p.c2 = c2;
+    p.c1 = c1;
+    const bool save = c2.save_gates != 0;
+    const long long t16 = (long long)n_img * cdiv(c2.H, 16) * cdiv(c2.W, 32);
+    if (t16 >= 512) return save ? launch_pair_th<16, true>(p, n_img, st) : launch_pair_th<16, false>(p, n_img, st);
+    return save ? launch_pair_th<8, true>(p, n_img, st) : launch_pair_th<8, false>(p, n_img, st);
 }
 
 static int cell_fwd_cb8(const void* x, const void* h, const float* c_in, const void* wpk, const float* bpk,
@@ -934,11 +997,18 @@ extern "C" int plc_generator_rollout_fwd(const plc_rollout_desc* d, void* stream
             pa.c1.sync = pa.c2.sync = (unsigned*)(ws + p.sync);
             if ((rc = launch_persistent(pa, B, T, save, st, &persistent))) return rc;
         }
-        if (!persistent)
+        if (!persistent && fast && T > 1 && !plc_no_pairing()) {
+            // cell 1 (0) | cell 2 (t-1) + cell 1 (t), t = 1 .. T-1 | cell 2 (T-1)
+            if ((rc = launch_cell(cell1(0), B, C1, C1, st))) return rc;
+            for (int t = 1; t < T; ++t)
+                if ((rc = launch_pair(cell2(t - 1), cell1(t), B, st))) return rc;
+            if ((rc = launch_cell(cell2(T - 1), B, C1, C2, st))) return rc;
+        } else if (!persistent) {
             for (int t = 0; t < T; ++t) {
                 if ((rc = launch_cell(cell1(t), B, C1, C1, st))) return rc;
                 if ((rc = launch_cell(cell2(t), B, C1, C2, st))) return rc;
             }
+        }
     }
 
     // ---- everything after the recurrence is batched over the T*B frames ----------------------
