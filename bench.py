@@ -414,6 +414,11 @@ def main():
             res["roofline_mfma"] = mfma_roof
         else:
             res["roofline"] = mfma_roof
+        if hidden != [16, 32]:
+            note = "timed at hidden_dims [16,32]: the instantiated kernels, not the run-time-width ones this run used"
+            for k in ("roofline", "roofline_mfma"):
+                if k in res:
+                    res[k]["note"] = note
         if not args.no_cpu_baseline and world == 1:
             params = {k: v.detach().cpu() for k, v in model.state_dict().items()}
             res["cpu_baseline"] = cpu_baseline(args.mode, B, T, H, W, s, params)
