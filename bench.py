@@ -51,9 +51,9 @@ CELL2_BYTES_PER_PX = 416          # x 32 + h 64 + c 128 read, h' 64 + c' 128 wri
 PEAK_BF16 = 2.5e15                # dense bf16 MFMA peak of MI355X, FLOP/s
 PEAK_FP8 = 5.0e15                 # dense fp8 peak (block-scaled MFMA), FLOP/s
 PEAK_HBM = 8.0e12                 # HBM3E peak of MI355X, B/s
-# pointwise LSTM backward, per 8-channel unit of one pixel: two dh (bf16) 32 + dc' (fp32) 32 + c (fp32) 32
-# + gates i,f,o,g (bf16) 64 read; dz (bf16) 64 + dc (fp32) 32 written
-PW_BWD_BYTES_PER_UNIT = 256
+# pointwise LSTM backward, per 8-channel unit of one pixel: two dh (bf16) 32 + dc' (bf16) 16 + c (fp32) 32
+# + gates i,f,o,g (bf16) 64 read; dz (bf16) 64 + dc (bf16) 16 written
+PW_BWD_BYTES_PER_UNIT = 224
 N_STATIONS = 35
 
 
@@ -157,14 +157,14 @@ def time_pointwise_bwd_kernel(B, H, W, device, Ch=32, iters=50):
     for _ in range(4):
         gates = torch.rand(B, 4 * ncb, H, W, 8, device=device).to(torch.bfloat16).view(torch.int16)
         c_prev = torch.randn(B, ncb, H, W, 8, device=device)
-        sets.append((bf(B, ncb, H, W, 8), bf(B, ncb, H, W, 8), torch.randn(B, ncb, H, W, 8, device=device), gates,
-                     c_prev, torch.empty_like(gates), torch.empty_like(c_prev)))
+        sets.append((bf(B, ncb, H, W, 8), bf(B, ncb, H, W, 8), bf(B, ncb, H, W, 8), gates,
+                     c_prev, torch.empty_like(gates), bf(B, ncb, H, W, 8)))
     img = ncb * H * W * 16
     st = ops._stream()
 
     def run(k):
         dh0, dh1, dc_in, gates, c_prev, dz, dc = sets[k % len(sets)]
-        _lib.check(L.plc_lstm_pointwise_bwd(dh0.data_ptr(), img, dh1.data_ptr(), img, None, 0, dc_in.data_ptr(),
+        _lib.check(L.plc_lstm_pointwise_bwd_bf16dc(dh0.data_ptr(), img, dh1.data_ptr(), img, None, 0, dc_in.data_ptr(),
                                             gates.data_ptr(), c_prev.data_ptr(), dz.data_ptr(), dc.data_ptr(),
                                             B, Ch, H, W, st), "pointwise_bwd")
     for k in range(5):
@@ -404,7 +404,7 @@ def main():
             tp = time_pointwise_bwd_kernel(B, H, W, device)
             pw_bytes = PW_BWD_BYTES_PER_UNIT * B * 4 * H * W          # cell 2: 4 channel blocks per pixel
             pw_traffic = None
-            pj = os.path.join(ROOT, "profiles", "r1_pointwise_bwd_traffic.json")
+            pj = os.path.join(ROOT, "profiles", "r2_pointwise_bwd_traffic.json")
             if os.path.exists(pj) and args.config == "c3":
                 pw_traffic = json.load(open(pj)).get("hbm_bytes_per_launch")
             res["roofline"] = {"bound": "hbm", "kernel": "plc_lstm_pointwise_bwd_kernel (cell 2, one timestep)",

@@ -220,6 +220,13 @@ int plc_convlstm_cell_bwd(const float* x, const float* h, const float* c,
 int plc_lstm_pointwise_bwd(const void* dh0, long long dh0_image_bytes, const void* dh1, long long dh1_image_bytes,
                            const void* dh2, long long dh2_image_bytes, const float* dc_next, const void* gates,
                            const float* c_prev, void* dz, float* dc, int B, int Ch, int H, int W, void* stream);
+/* The form the rollout's backward pass uses: dL/dc travels between time steps as bf16 CB8 (16-byte units)
+ * like every other gradient tensor of the pass (dh, dz), which takes 32 of the 256 bytes per unit off
+ * the kernel (the parameter gradients do not move: the rounding is unbiased and they are sums over
+ * millions of pixels).  dc_next / dc: CB8 bf16 [B][Ch/8]; everything else as above.  224 bytes per unit. */
+int plc_lstm_pointwise_bwd_bf16dc(const void* dh0, long long dh0_image_bytes, const void* dh1, long long dh1_image_bytes,
+                                  const void* dh2, long long dh2_image_bytes, const void* dc_next, const void* gates,
+                                  const float* c_prev, void* dz, void* dc, int B, int Ch, int H, int W, void* stream);
 
 typedef struct plc_rollout_grads {
     const float* grad_out;   /* dL/d out, fp32 [B][T][1][out_H][out_W] */

@@ -200,9 +200,11 @@ static Cb8View view(const void* p, long long img) {
 
 static int lstm_pointwise_bwd(Cb8View dh0, Cb8View dh1, Cb8View dh2, const void* dc_in, const void* gates,
                               const void* c_prev, const void* c_cur, void* dz, void* dc_out, int B, int Ch, int H,
-                              int W, hipStream_t st, Cb8View dh0_mul = Cb8View{nullptr, 0}) {
+                              int W, hipStream_t st, Cb8View dh0_mul = Cb8View{nullptr, 0}, int dc_bf16 = 0) {
     LstmBwdArgs a;
     a.B = B; a.ncb = Ch / 8; a.H = H; a.W = W;
+    // (PLC_DC_FP32 in the environment keeps the rollout's dc in fp32: A/B timing and accuracy checks)
+    a.dc_bf16 = dc_bf16 && !getenv("PLC_DC_FP32");
     a.dh0 = dh0; a.dh1 = dh1; a.dh2 = dh2;
     a.dh0_mul = dh0_mul;
     a.dc_in = (const char*)dc_in; a.gates = (const char*)gates;
@@ -291,6 +293,18 @@ extern "C" int plc_lstm_pointwise_bwd(const void* dh0, long long dh0_image_bytes
     PLC_REQUIRE(Ch > 0 && Ch % 8 == 0, "plc_lstm_pointwise_bwd: Ch must be a positive multiple of 8");
     return lstm_pointwise_bwd(view(dh0, dh0_image_bytes), view(dh1, dh1_image_bytes), view(dh2, dh2_image_bytes),
                               dc_next, gates, c_prev, nullptr, dz, dc, B, Ch, H, W, (hipStream_t)stream);
+}
+
+extern "C" int plc_lstm_pointwise_bwd_bf16dc(const void* dh0, long long dh0_image_bytes, const void* dh1,
+                                             long long dh1_image_bytes, const void* dh2, long long dh2_image_bytes,
+                                             const void* dc_next, const void* gates, const float* c_prev, void* dz,
+                                             void* dc, int B, int Ch, int H, int W, void* stream) {
+    PLC_REQUIRE(gates && dz && dc, "plc_lstm_pointwise_bwd_bf16dc: null pointer");
+    PLC_REQUIRE(B > 0 && H > 0 && W > 0, "plc_lstm_pointwise_bwd_bf16dc: non-positive size");
+    PLC_REQUIRE(Ch > 0 && Ch % 8 == 0, "plc_lstm_pointwise_bwd_bf16dc: Ch must be a positive multiple of 8");
+    return lstm_pointwise_bwd(view(dh0, dh0_image_bytes), view(dh1, dh1_image_bytes), view(dh2, dh2_image_bytes),
+                              dc_next, gates, c_prev, nullptr, dz, dc, B, Ch, H, W, (hipStream_t)stream,
+                              Cb8View{nullptr, 0}, 1);
 }
 
 extern "C" size_t plc_convlstm_cell_bwd_workspace_bytes(int B, int Cin, int Ch, int H, int W) {
@@ -656,7 +670,7 @@ extern "C" int plc_generator_rollout_bwd(const plc_rollout_desc* d, const plc_ro
                                      t == 0 ? nullptr : wf + fp.c2s + (size_t)t * s2 * 2,     // c_{-1} = 0 is not stored
                                      wf + fp.c2s + (size_t)(t + 1) * s2 * 2, dz2_t,
                                      dc2_t, B, C2, H, W, st,
-                                     direct ? view(wf + fp.gate, fp.img2) : view(nullptr, 0))))
+                                     direct ? view(wf + fp.gate, fp.img2) : view(nullptr, 0), 1)))
             return rc;
         if ((rc = cell_dgrad(dz2_t, wb + bp.cell2T, bpk0, dcat2_t, B, C1, C2, H, W, st))) return rc;
 
@@ -669,7 +683,7 @@ extern "C" int plc_generator_rollout_bwd(const plc_rollout_desc* d, const plc_ro
                                      view(nullptr, 0), last ? nullptr : dc1_n, wf + fp.gates1 + (size_t)t * s1 * 4,
                                      t == 0 ? nullptr : wf + fp.c1s + (size_t)t * s1 * 2,
                                      wf + fp.c1s + (size_t)(t + 1) * s1 * 2, dz1_t,
-                                     dc1_t, B, C1, H, W, st)))
+                                     dc1_t, B, C1, H, W, st, view(nullptr, 0), 1)))
             return rc;
         if ((rc = cell_dgrad(dz1_t, wb + bp.cell1T, bpk0, dcat1_t, B, C1, C1, H, W, st))) return rc;
     }

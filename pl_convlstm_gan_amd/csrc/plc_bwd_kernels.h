@@ -49,12 +49,13 @@ struct LstmBwdArgs {
     Cb8View dh0_mul;               // optional (p null = none): dh0 is taken as bf16(dh0 * dh0_mul), e.g. the
                                    // gradient of the gated feature map times the gate, formed here instead of
                                    // being written out and read back
-    const char* dc_in;             // fp32 CB8 [B][ncb] or null
+    int dc_bf16;                   // dc_in / dc_out are bf16 CB8 (16-byte units) instead of fp32 CB8 (32-byte units)
+    const char* dc_in;             // fp32 (or bf16) CB8 [B][ncb] or null
     const char* gates;             // bf16 CB8 [B][4*ncb]
     const char* c_prev;            // fp32 CB8 [B][ncb] or null (= zeros: the first timestep)
     const char* c_cur;             // fp32 CB8 [B][ncb] (not read: c_t is rebuilt from gates and c_prev)
     char* dz;                      // bf16 CB8 [B][4*ncb]
-    char* dc_out;                  // fp32 CB8 [B][ncb]
+    char* dc_out;                  // fp32 (or bf16) CB8 [B][ncb]
 };
 
 __global__ void plc_lstm_pointwise_bwd_kernel(const LstmBwdArgs a) {
@@ -89,7 +90,7 @@ __global__ void plc_lstm_pointwise_bwd_kernel(const LstmBwdArgs a) {
         const long long su = (b * a.ncb) * hw + u;              // unit index in [B][ncb] tensors
         const long long gu = (b * 4 * a.ncb) * hw + u;          // unit index of gate 0 in [B][4 ncb]
         F8 dcin;
-        if (a.dc_in) dcin = ld_f8(a.dc_in + su * 32);
+        if (a.dc_in) dcin = a.dc_bf16 ? ld_bf8(a.dc_in + su * 16) : ld_f8(a.dc_in + su * 32);
         else {
 #pragma unroll
             for (int j = 0; j < 8; ++j) dcin.v[j] = 0.0f;
@@ -121,7 +122,8 @@ __global__ void plc_lstm_pointwise_bwd_kernel(const LstmBwdArgs a) {
         st_bf8(a.dz + (gu + 1 * a.ncb * hw) * 16, zf);
         st_bf8(a.dz + (gu + 2 * a.ncb * hw) * 16, zo);
         st_bf8(a.dz + (gu + 3 * a.ncb * hw) * 16, zg);
-        st_f8(a.dc_out + su * 32, dcp);
+        if (a.dc_bf16) st_bf8(a.dc_out + su * 16, dcp);
+        else st_f8(a.dc_out + su * 32, dcp);
     }
 }
 
