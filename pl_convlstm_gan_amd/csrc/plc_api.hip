@@ -10,6 +10,7 @@
 #include "../../include/plconvlstm.h"
 #include "plc_conv_kernel.h"
 #include "plc_convg_kernel.h"
+#include "plc_convr_kernel.h"
 #include "plc_misc_kernels.h"
 #include "plc_fp8_kernels.h"
 
@@ -279,6 +280,48 @@ static int launch_conv(ConvArgs a, int n_img, int n_mgroups, hipStream_t st) {
     // (single-M-tile convs whose staging is not plain DMA were measured faster with 8-row tiles)
     if (t16 >= 512 && !(NMT == 1 && STAGE != STAGE_CB8)) return launch_conv_th<NCB0, NCB1, NMT, KS, STAGE, EPI, 16>(a, n_img, n_mgroups, st);
     return launch_conv_th<NCB0, NCB1, NMT, KS, STAGE, EPI, 8>(a, n_img, n_mgroups, st);
+}
+
+// Debugging / measurement switch: PLC_NO_ROLLING=1 keeps the tile-at-a-time kernels where a rolling-window
+// instantiation exists (results are bit-identical either way).
+static bool plc_no_rolling() {
+    static const bool off = [] { const char* e = getenv("PLC_NO_ROLLING"); return e && *e && *e != '0'; }();
+    return off;
+}
+
+// The rolling-window kernel (plc_convr_kernel.h): the image is cut into 32-column strips and each strip
+// into segments of seg_rows rows, one workgroup per segment, as many segments as workgroups stay
+// resident (a single round) when the image is large enough for that.
+template <int NCB, int NMT, int STAGE, int EPI, int KSPLIT, bool PLAIN = false>
+static int launch_convr(ConvArgs a, int n_img, int n_mgroups, hipStream_t st) {
+    using R = PlcRoll<NCB, NMT, KSPLIT>;
+    constexpr int lds = plc_convr_lds_bytes<NCB, NMT, KSPLIT, STAGE>();
+    auto kern = plc_convr_kernel<NCB, NMT, STAGE, EPI, KSPLIT, PLAIN>;
+    if (PLAIN && (EPI != EPI_ACT_CB8 || a.out1.p || a.mul.p || a.act == ACT_SIGMOID))
+        return plc_fail(PLC_EINVAL, "conv: plain epilogue requested with a second output, multiplier or sigmoid");
+    if (lds > 65536) {
+        static bool lds_raised[64] = {false};
+        int rc = ensure_lds_limit((const void*)kern, lds, lds_raised);
+        if (rc) return rc;
+    }
+    // (the kernel addresses a lane's unit of an input row with a 32-bit offset from the row's base)
+    if ((long long)NCB * a.H * a.W * 16 >= (1ll << 32)) return plc_fail(PLC_EINVAL, "conv: image too large for the rolling-window kernel");
+    constexpr int by_lds = (160 * 1024) / lds;
+    const int resident = cu_count() * (by_lds < 2 ? by_lds : 2) / n_mgroups;
+    a.tiles_x = cdiv(a.W, 32);
+    const long long strips = (long long)n_img * a.tiles_x;
+    const long long want = strips < resident ? resident / strips : 1;     // segments per strip
+    int seg_rows = cdiv(cdiv(a.H, (int)want), R::A) * R::A;
+    if (seg_rows < 2 * R::A) seg_rows = 2 * R::A;
+    a.seg_rows = seg_rows;
+    a.tiles_y = cdiv(a.H, seg_rows);
+    const long long segs = strips * a.tiles_y;
+    if (segs <= 0 || segs >= (1ll << 31)) return plc_fail(PLC_EINVAL, "conv: bad segment count %lld", segs);
+    a.n_tiles = (int)segs;
+    a.n_blocks = segs < resident ? (int)segs : resident;
+    hipLaunchKernelGGL(kern, dim3(a.n_blocks, n_mgroups), dim3(256), lds, st, a);
+    PLC_HIP(hipGetLastError());
+    return PLC_OK;
 }
 
 // The run-time-width kernel: ncb0 / ncb1 input channel blocks from src0 / src1, n_mt 32-row output tiles.

@@ -227,8 +227,12 @@ static int cell_dgrad(const void* dz, const void* wpkT, const float* bpk0, void*
     a.bpk = bpk0;
     a.act = ACT_NONE;
     a.ncb_out = (Cin + Ch) / 8;
-    if (Cin == 16 && Ch == 16) return launch_conv_th<8, 0, 1, 3, STAGE_CB8, EPI_ACT_CB8, 8, 1>(a, B, 1, st);
-    if (Cin == 16 && Ch == 32) return launch_conv_th<16, 0, 2, 3, STAGE_CB8, EPI_ACT_CB8, 4, 2>(a, B, 1, st);
+    if (Cin == 16 && Ch == 16)
+        return plc_no_rolling() ? launch_conv_th<8, 0, 1, 3, STAGE_CB8, EPI_ACT_CB8, 8, 1>(a, B, 1, st)
+                                : launch_convr<8, 1, STAGE_CB8, EPI_ACT_CB8, 1, true>(a, B, 1, st);
+    if (Cin == 16 && Ch == 32)
+        return plc_no_rolling() ? launch_conv_th<16, 0, 2, 3, STAGE_CB8, EPI_ACT_CB8, 4, 2>(a, B, 1, st)
+                                : launch_convr<16, 2, STAGE_CB8, EPI_ACT_CB8, 2, true>(a, B, 1, st);
     if (Cin % 8 == 0 && Ch % 8 == 0)
         return launch_convg<3, STAGE_CB8, EPI_ACT_CB8>(a, 4 * Ch / 8, 0, cdiv(Cin + Ch, 32), B, st);
     return plc_fail(PLC_EUNSUPPORTED, "ConvLSTM cell backward (Cin=%d, Ch=%d): channel counts must be multiples of 8", Cin, Ch);

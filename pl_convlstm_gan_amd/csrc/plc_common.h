@@ -31,8 +31,12 @@ __device__ __forceinline__ unsigned short f2bf(float f) {
 __device__ __forceinline__ float bf2f(unsigned short u) {
     return __builtin_bit_cast(float, (unsigned)u << 16);
 }
+typedef float plc_f32x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 plc_bf16x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ unsigned pack_bf2(float lo, float hi) {
-    return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
+    // one v_cvt_pk_bf16_f32 (two scalar conversions plus shift/or otherwise)
+    const plc_f32x2_t f = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f, plc_bf16x2_t));
 }
 __device__ __forceinline__ uint2 pack_bf4(float a, float b, float c, float d) {
     return make_uint2(pack_bf2(a, b), pack_bf2(c, d));

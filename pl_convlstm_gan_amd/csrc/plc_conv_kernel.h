@@ -71,6 +71,7 @@ struct ConvArgs {
     int mul_mode;        // EPI_ACT_CB8 with `mul`: MUL_PRODUCT (v *= m) or MUL_RELU_MASK (v = m > 0 ? v : 0)
     int g_ncb0, g_ncb1;  // run-time-width kernel (plc_convg_kernel.h) only: channel blocks of src0 / src1
     int g_nmt;           // ... and the conv's 32-row output tiles
+    int seg_rows;        // rolling-window kernel (plc_convr_kernel.h) only: rows per segment
     unsigned* sync;      // persistent recurrence (PERSIST != 0): the device-wide barrier's counter, zero at launch
     PlcTensor src0;      // CB8 bf16, first NCB0 channel blocks   (STAGE_COORD / STAGE_F32_1CH: fp32 plane)
     PlcTensor src1;      // CB8 bf16, next NCB1 channel blocks
@@ -153,7 +154,10 @@ __device__ __forceinline__ uint4 plc_stage_unit(const ConvArgs& a, const char* s
 
 // Epilogue of one pixel row of one 32-row output tile: acc register 4g+j = row 8g + 4*half + j.
 // FULL = the whole tile lies inside the image (no per-lane bounds check, hence no branch).
-template <int EPI, bool FULL = false>
+// PLAIN (EPI_ACT_CB8 only) = the caller guarantees no second output, no multiplier and no sigmoid: the
+// epilogue then contains no load at all (a load on any path makes the compiler wait for outstanding
+// vector-memory operations wherever its destination registers are reused).
+template <int EPI, bool FULL = false, bool PLAIN = false>
 __device__ __forceinline__ void plc_epilogue(const ConvArgs& a, const f32x16_t& acc, int n, int mt, int n_mt,
                                              int gy, int gx, int half, const float4& cp) {
     const int H = a.H, W = a.W;
@@ -195,7 +199,7 @@ __device__ __forceinline__ void plc_epilogue(const ConvArgs& a, const f32x16_t& 
         // group that was ~50 branches per stored row (1.4 us per pass of the cell-2 data-gradient
         // conv).  The common case -- no second output, no multiplier, identity or ReLU -- is decided
         // once per row and then runs straight-line.
-        if (!op1 && !mp && a.act != ACT_SIGMOID) {
+        if (PLAIN || (!op1 && !mp && a.act != ACT_SIGMOID)) {
             char* const o = op + pix * 16 + half * 8;
             const int n_cb = a.ncb_out - 4 * mt;          // channel blocks of this M tile that are stored
             auto row = [&](auto relu_c) {

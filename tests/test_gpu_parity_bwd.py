@@ -142,3 +142,36 @@ def test_generator_param_grads_through_bilinear_resize(gpu, name, n_blocks, ctor
                            fwd_kw=dict(emulate="bf16", **ctor, **fwd_kw))
     for k, v in grads.items():
         assert relmax(v, emu[k]) <= 2e-2 and rel_l2(v, emu[k]) <= 2e-2, (k, relmax(v, emu[k]), rel_l2(v, emu[k]))
+
+
+@pytest.mark.parametrize("B,cin,ch,H,W", [
+    (1, 16, 32, 5, 32 * 515),      # more 32-column strips than workgroups stay resident: several segments per workgroup
+    (1, 16, 16, 9, 32 * 515 - 10),  # the same for the cell-1 form (8 rows per pass), ragged last strip
+    (3, 16, 32, 37, 70),           # several segments per strip, the last one partial, ragged width
+    (2, 16, 16, 37, 70),
+    (2, 16, 32, 3, 33),            # fewer rows than one segment
+])
+def test_cell_data_gradient_segment_walk(gpu, B, cin, ch, H, W):
+    """dx / dh / dc of one ConvLSTM cell step (convlstm.py:16-29) at shapes that exercise the rolling-window
+    data-gradient conv's segment walk, against autograd of the oracle cell with bf16-rounded operands.
+    Bounds as for the golden cell case: max|diff| <= 5e-2 * max|ref|, relative L2 <= 3e-2."""
+    from pl_convlstm_gan_amd import ConvLSTMCell
+    gen = torch.Generator().manual_seed(H * 1000 + W)
+    x = torch.randn(B, cin, H, W, generator=gen)
+    h = torch.randn(B, ch, H, W, generator=gen) * 0.5
+    c = torch.randn(B, ch, H, W, generator=gen)
+    w = torch.randn(4 * ch, cin + ch, 3, 3, generator=gen) * 0.06
+    b = torch.randn(4 * ch, generator=gen) * 0.1
+    rh, rc = torch.randn(B, ch, H, W, generator=gen), torch.randn(B, ch, H, W, generator=gen)
+    leaf = [t.clone().requires_grad_(True) for t in (x, h, c)]
+    h2o, c2o = O.convlstm_cell(leaf[0], leaf[1], leaf[2], w, b, emulate="bf16")
+    ((h2o * rh).sum() + (c2o * rc).sum()).backward()
+    cell = ConvLSTMCell(cin, ch)
+    cell.load_state_dict({"conv.weight": w, "conv.bias": b})
+    cell = cell.to(gpu)
+    xg, hg, cg = (t.to(gpu).requires_grad_(True) for t in (x, h, c))
+    h2, c2 = cell(xg, hg, cg)
+    ((h2 * rh.to(gpu)).sum() + (c2 * rc.to(gpu)).sum()).backward()
+    for name, got, ref in (("dx", xg.grad, leaf[0].grad), ("dh", hg.grad, leaf[1].grad), ("dc", cg.grad, leaf[2].grad)):
+        assert relmax(got.cpu(), ref) <= TOL, (name, relmax(got.cpu(), ref))
+        assert rel_l2(got.cpu(), ref) <= TOL_L2, (name, rel_l2(got.cpu(), ref))
