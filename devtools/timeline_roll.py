@@ -18,7 +18,7 @@ dev = torch.device("cuda:0")
 st = torch.cuda.current_stream().cuda_stream
 
 
-def cell_bwd(B, Cin, Ch, H, W):
+def cell_bwd(B, Cin, Ch, H, W, sel=777, waves=4, names=None):
     g = torch.Generator(device="cpu").manual_seed(1)
     mk = lambda *s: torch.randn(*s, generator=g).to(dev)
     x, h, c = mk(B, Cin, H, W), mk(B, Ch, H, W), mk(B, Ch, H, W)
@@ -27,7 +27,7 @@ def cell_bwd(B, Cin, Ch, H, W):
     dx, dh, dc = torch.empty_like(x), torch.empty_like(h), torch.empty_like(c)
     dw, db = torch.empty_like(w), torch.empty_like(b)
     ws = torch.empty(L.plc_convlstm_cell_bwd_workspace_bytes(B, Cin, Ch, H, W), dtype=torch.uint8, device=dev)
-    tl = torch.zeros(1024 * 4 * 10, dtype=torch.int64, device=dev)
+    tl = torch.zeros(1024 * waves * 10, dtype=torch.int64, device=dev)
 
     def run():
         _lib.check(L.plc_convlstm_cell_bwd(x.data_ptr(), h.data_ptr(), c.data_ptr(), w.data_ptr(), b.data_ptr(), dhn.data_ptr(),
@@ -36,20 +36,23 @@ def cell_bwd(B, Cin, Ch, H, W):
     for _ in range(3):
         run()
     torch.cuda.synchronize()
-    L.plc_debug_select_timeline(777)
+    L.plc_debug_select_timeline(sel)
     L.plc_debug_set_timeline(tl.data_ptr())
     run()
     torch.cuda.synchronize()
     L.plc_debug_set_timeline(None)
-    raw = tl.cpu().numpy().reshape(-1, 4, 10).astype(np.float64) / 100.0
+    raw = tl.cpu().numpy().reshape(-1, waves, 10).astype(np.float64) / 100.0
     raw = raw[raw[:, 0, 9] > 0]
     t0 = raw[:, :, 0].min()
-    print(f"cell ({Cin},{Ch}) data gradient, B={B} {H}x{W}: {raw.shape[0]} workgroups, kernel span {raw[:, :, 9].max() - t0:.2f} us")
+    print(f"cell ({Cin},{Ch}) {'data' if sel == 777 else 'weight'} gradient, B={B} {H}x{W}: {raw.shape[0]} workgroups, kernel span {raw[:, :, 9].max() - t0:.2f} us")
     print(f"  wave lifetime mean {(raw[:, :, 9] - raw[:, :, 0]).mean():.2f} us; start spread {raw[:, :, 0].max() - t0:.2f} us")
-    for k, nm in [(1, "prologue (weights, window 0)"), (2, "MFMA loops"), (3, "exchange barrier + partial writes"),
+    for k, nm in names or [(1, "prologue (weights, window 0)"), (2, "MFMA loops"), (3, "exchange barrier + partial writes"),
                   (4, "wait for rows in flight"), (5, "barrier"), (7, "partial-sum reads"), (8, "next request"), (6, "epilogue stores")]:
         col = raw[:, :, k]
         print(f"  {nm:36s} mean {col.mean():6.2f}  min {col.min():6.2f}  max {col.max():6.2f} us per wave")
 
 
 cell_bwd(4, 16, 32, 256, 256)
+cell_bwd(40, 16, 32, 256, 256, sel=778, waves=8,
+         names=[(1, "first tile"), (2, "next tile's loads requested"), (3, "MFMA loop"), (4, "wait for the loads"),
+                (5, "registers -> LDS"), (6, "barrier")])

@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libplconvlstm.so")
+# (PLC_LIB_PATH: load another build of the library instead, e.g. an older one for a same-box comparison)
+LIB_PATH = os.environ.get("PLC_LIB_PATH") or os.path.join(_HERE, "libplconvlstm.so")
 
 EXPORTS = (
     "plc_version", "plc_last_error",

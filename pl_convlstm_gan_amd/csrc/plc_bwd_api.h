@@ -80,9 +80,20 @@ static int launch_wgrad(ConvArgs in, PlcTensor dz, int mcb_valid, int n_img, Sla
     if (dz_mask) a.dz_mask = *dz_mask;
     a.mcb_valid = mcb_valid;
     a.rows_valid = cout;
-    a.n_tiles = n_img * a.in.tiles_x * a.in.tiles_y;
-    a.slab = slab;
+    // (the kernel addresses a lane's unit with a 32-bit offset from the tile's origin in its tensor)
+    {
+        const int blocks = NCB0 > NCB1 ? (NCB0 > 4 * MT ? NCB0 : 4 * MT) : (NCB1 > 4 * MT ? NCB1 : 4 * MT);
+        if ((long long)(blocks + 1) * in.H * in.W * 16 >= (1ll << 32))
+            return plc_fail(PLC_EINVAL, "wgrad: image %d x %d too large (a tensor of %d channel blocks must stay below 4 GiB)", in.H, in.W, blocks);
+    }
+    // vertical segments of up to 16 tiles; shorter ones when that leaves workgroups without work
     const int max_blocks = wgrad_max_blocks<NCB0, NCB1, MT, KS>();
+    // (the coord-conv staging reads 4 bytes per pixel: nothing to share, and its tiles are best walked row by row)
+    int seg_tiles = STAGE == STAGE_COORD ? 1 : (a.in.tiles_y < 16 ? a.in.tiles_y : 16);
+    while (seg_tiles > 1 && (long long)n_img * a.in.tiles_x * cdiv(a.in.tiles_y, seg_tiles) < max_blocks) seg_tiles = (seg_tiles + 1) / 2;
+    a.seg_tiles = seg_tiles;
+    a.n_tiles = n_img * a.in.tiles_x * cdiv(a.in.tiles_y, seg_tiles);
+    a.slab = slab;
     const int grid = a.n_tiles < max_blocks ? a.n_tiles : max_blocks;
     auto kern = plc_wgrad_kernel<NCB0, NCB1, MT, KS, STAGE>;
     {

@@ -20,13 +20,14 @@
 
 #ifdef PLC_TIMELINE
 // Instrumented build only: per wave, the time spent in each phase of the pass loop, summed over the
-// passes (100 MHz ticks), is left in plc_timeline[(block * 4 + wave) * 10 + k] when plc_timeline_sel == 777.
+// passes (100 MHz ticks), is left in plc_timeline[(block * waves + wave) * 10 + k] when plc_timeline_sel == id
+// (777: this kernel, 778: the weight-gradient kernel).
 #define PLC_RT_DECL() long long rt_[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}; long long rt_last_ = (long long)wall_clock64(); const long long rt_t0_ = rt_last_
 #define PLC_RT(k) do { const long long now_ = (long long)wall_clock64(); rt_[k] += now_ - rt_last_; rt_last_ = now_; } while (0)
-#define PLC_RT_FLUSH()                                                                                  \
+#define PLC_RT_FLUSH(id_)                                                                               \
     do {                                                                                                \
-        if (plc_timeline && plc_timeline_sel == 777 && (threadIdx.x & 63) == 0) {                       \
-            long long* o_ = plc_timeline + ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 10;       \
+        if (plc_timeline && plc_timeline_sel == (id_) && (threadIdx.x & 63) == 0) {                     \
+            long long* o_ = plc_timeline + ((long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 10; \
             o_[0] = rt_t0_; o_[9] = (long long)wall_clock64();                                          \
             for (int k_ = 1; k_ < 9; ++k_) o_[k_] = rt_[k_];                                            \
         }                                                                                               \
@@ -34,7 +35,7 @@
 #else
 #define PLC_RT_DECL() do {} while (0)
 #define PLC_RT(k) do {} while (0)
-#define PLC_RT_FLUSH() do {} while (0)
+#define PLC_RT_FLUSH(id_) do {} while (0)
 #endif
 
 template <int NCB, int NMT, int KSPLIT>
@@ -381,5 +382,5 @@ __global__ __launch_bounds__(256, 2) void plc_convr_kernel(const ConvArgs a) {
 #undef PLC_ROLL_ISSUE
 #undef PLC_ROLL_EPI
     }
-    PLC_RT_FLUSH();
+    PLC_RT_FLUSH(777);
 }

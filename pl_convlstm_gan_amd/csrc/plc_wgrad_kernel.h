@@ -8,9 +8,14 @@
 // ds_read_b64_tr_b16 (the transposing LDS read): a 16-lane group reads a 4-pixel x 16-channel
 // block and every lane receives 4 consecutive pixels of its own channel.
 //
-//   * one persistent workgroup of 8 waves per CU walks 4 x 32 pixel tiles; each tile's dz block
-//     and (4+2) x 34 input halo block are double-buffered in LDS (next tile's global loads are in
-//     flight while the current tile is contracted);
+//   * one persistent workgroup of 8 waves per CU walks 4 x 32 pixel tiles in vertical SEGMENTS of
+//     seg_tiles tiles (segments b, b + gridDim.x, ...; neighbouring workgroups take horizontally
+//     neighbouring segments, so the tiles in flight at any moment cover whole image rows: taking a
+//     contiguous run of tiles per workgroup instead scatters them over the image and was measured 15 %
+//     slower).  Each tile's dz block and (4+2) x 34 input halo block are double-buffered in LDS (next
+//     tile's global loads are in flight while the current tile is contracted), and the two input rows
+//     that a tile shares with the one above it in its segment are copied from the other LDS buffer
+//     instead of being fetched again (a third of the input bytes);
 //   * the whole dW of the conv stays in registers for the kernel's lifetime: wave (m, g) owns the
 //     32-row output tile m and NT_W 32-column tiles (f32x16 accumulators);
 //   * a column group is 16 input channels at one tap; one extra group whose B operand is the
@@ -19,7 +24,7 @@
 //     slabs in a fixed order (bitwise reproducible, no atomics) and scatters into the PyTorch
 //     weight layout.
 #pragma once
-#include "plc_conv_kernel.h"
+#include "plc_convr_kernel.h"
 #include "plc_misc_kernels.h"
 
 typedef __attribute__((__vector_size__(4 * sizeof(short)))) short s16x4_t;
@@ -35,7 +40,8 @@ struct WgradArgs {
     PlcTensor dz_mask; // optional (p may be null): CB8 bf16 like dz; dz counts only where mask > 0 (ReLU backward)
     int mcb_valid;     // channel blocks present in dz
     int rows_valid;    // output channels of the conv: slab rows that are written (and later reduced)
-    int n_tiles;       // n_img * tiles_y * tiles_x
+    int n_tiles;       // number of segments: n_img * ceil(tiles_y / seg_tiles) * tiles_x
+    int seg_tiles;     // tiles of a vertical segment
     float* slab;       // [gridDim.x][MT*32][NT*32]
 };
 
@@ -76,7 +82,6 @@ struct WgradGeom {
     static constexpr int CONST_BASE = IN_UNITS + DZ_LDS_UNITS;
     static constexpr int BUF_UNITS = CONST_BASE + 2 * CONST_UNITS;   // [in | dz | zeros | ones]
     static constexpr int LDS_BYTES = 2 * BUF_UNITS * 16;
-    static constexpr int NPF = (IN_UNITS + DZ_UNITS + 511) / 512;
 };
 
 // Waves per SIMD to compile for: the instantiations whose LDS double buffer lets two workgroups share a
@@ -145,89 +150,136 @@ __global__ __launch_bounds__(512, (plc_wgrad_min_waves<NCB0 + NCB1, MT, KS>())) 
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
 
-    const int tiles_per_img = a.in.tiles_x * a.in.tiles_y;
-
     // ---- tile loader: global -> registers, registers -> LDS ---------------------------------
     // Two phases.  load_tile only SELECTS per-lane addresses (a real one, or a 16-byte constant for
     // lanes outside the image) and then loads unconditionally, so no load sits in a divergent
-    // branch and all NPF (+ secondary) loads of a tile are in flight together while the current
-    // tile is contracted.  store_tile forms the LDS units from the landed registers: the gated
-    // product, the coord-conv unit, the ReLU-masked dz.
+    // branch and all loads of a tile are in flight together while the current tile is contracted.
+    // store_tile forms the LDS units from the landed registers: the gated product, the coord-conv
+    // unit, the ReLU-masked dz.
+    // All eight waves run the loader at the same time (right after the tile's barrier), so whatever
+    // it costs in instructions is time the matrix cores idle.  Everything about a lane's units that does
+    // not depend on the tile is therefore fixed once, before the tile loop: the units are dealt out in
+    // prefetch slots that each hold units of ONE tensor (src0, src1, dz; slot k of a group = units
+    // 512 k + tid), a slot's byte offset from the tile's origin is one VGPR, and which lanes load /
+    // copy is a 64-bit lane mask in scalar registers.  Per tile and slot there remain a 64-bit add and the
+    // select against the zero constant; only tiles that touch the image border test bounds per lane.
     static_assert(STAGE == STAGE_CB8 || STAGE == STAGE_CB8_GATED || STAGE == STAGE_COORD, "unsupported staging");
     constexpr bool HAS2 = STAGE != STAGE_CB8;       // secondary 16-byte load: gate (input part), ReLU mask (dz part)
-    constexpr int NPF_IN = (G::IN_UNITS + 511) / 512;             // prefetch slots that hold input-part lanes
-    constexpr int NPF2 = HAS2 ? G::NPF : 1;
-    constexpr int NPFC = STAGE == STAGE_COORD ? NPF_IN : 1;
-    uint4 pf[G::NPF], pf2[NPF2];
+    constexpr int IN0 = NCB0 * G::PLANE, IN1 = NCB1 * G::PLANE;
+    constexpr int S0 = (IN0 + 511) / 512, S1 = (IN1 + 511) / 512, SI = S0 + S1, SD = (G::DZ_UNITS + 511) / 512;
+    constexpr int NPF = SI + SD;
+    constexpr int NPF2 = HAS2 ? NPF : 1;
+    constexpr int NPFC = STAGE == STAGE_COORD ? SI : 1;
+    constexpr int ROWS_LOG = G::TH == 8 ? 8 : 7;     // log2(TH * 32)
+    static_assert(G::TH * 32 == (1 << ROWS_LOG), "tile rows must be 4 or 8");
+    static_assert(STAGE != STAGE_COORD || (SI == 1 && NCB1 == 0), "the coord staging has one input channel block");
+    uint4 pf[NPF], pf2[NPF2];
     float pf_rain[NPFC], pf_row[NPFC], pf_col[NPFC];
-    auto load_tile = [&](int t) {
-        const int n = t / tiles_per_img;
-        const int rem = t - n * tiles_per_img;
-        const int ty = rem / a.in.tiles_x, tx = rem - ty * a.in.tiles_x;
-        const int x0 = tx * 32, y0 = ty * G::TH;
-        const char* s0 = plc_img(a.in.src0, n, a.in.n_in);
-        const char* s1 = NCB1 > 0 ? plc_img(a.in.src1, n, a.in.n_in) : nullptr;
-        const char* gt = STAGE == STAGE_CB8_GATED ? plc_img(a.in.gate, n, a.in.n_in) : nullptr;
-        const char* dzp = plc_img(a.dz, n, a.in.n_in);
-        const bool has_mask = HAS2 && a.dz_mask.p != nullptr;
-        const char* mkp = has_mask ? plc_img(a.dz_mask, n, a.in.n_in) : nullptr;
-        const char* const z16 = (const char*)&plc_zero16;
-        const char* const o16 = (const char*)&plc_ones16;
-        const long long plane_b = (long long)H * W * 16;
+    const char* const z16 = (const char*)&plc_zero16;
+    const char* const o16 = (const char*)&plc_ones16;
+    unsigned poff[NPF];                 // byte offset of the lane's unit from the slot's tile origin
+    unsigned pyx[SI];                   // input slots: row | column << 8 inside the halo tile
+    unsigned long long m_load[NPF];     // lanes whose unit exists in its tensor
+    unsigned long long m_copy[SI];      // input slots: lanes whose unit lies in the rows shared with the tile above
+    {
+        const unsigned plane_b = (unsigned)H * (unsigned)W * 16u;    // (the launcher checks that every offset fits 32 bits)
 #pragma unroll
-        for (int k = 0; k < G::NPF; ++k) {
-            const int u = tid + k * 512;
-            const char* p1 = z16;
-            const char* p2 = o16;
-            const char* pr = z16;
-            const char* prow = z16;
-            const char* pcol = z16;
-            if (u < G::IN_UNITS) {
-                const int cb = u / G::PLANE;
-                const int r = u - cb * G::PLANE;
+        for (int k = 0; k < NPF; ++k) {
+            if (k < SI) {
+                const bool second = k >= S0;
+                const int v = tid + 512 * (second ? k - S0 : k);
+                const int cbl = v / G::PLANE, r = v - cbl * G::PLANE;
                 const int ly = r / G::LW, lx = r - ly * G::LW;
-                const int gy = y0 - G::PAD + ly, gx = x0 - G::PAD + lx;
-                const bool ok = (gy >= 0) & (gy < H) & (gx >= 0) & (gx < W) & (a.in.g_ncb0 == 0 || cb < a.in.g_ncb0);
-                const long long pix = (long long)gy * W + gx;
-                if (STAGE == STAGE_COORD) {
-                    pr = ok ? s0 + pix * 4 : z16;
-                    prow = ok ? (const char*)(a.in.row_tab + gy) : z16;
-                    pcol = ok ? (const char*)(a.in.col_tab + gx) : z16;
-                } else {
-                    const char* base = (NCB1 == 0 || cb < NCB0) ? s0 + cb * plane_b : s1 + (cb - NCB0) * plane_b;
-                    // zero_state: src1 of the first n_in images is the (unstored) zero initial state
-                    const bool skip = ((NCB1 > 0 && cb >= NCB0 && a.in.zero_state != 0) || a.in.zero_state == 2) && n < a.in.n_in;
-                    p1 = (ok & !skip) ? base + pix * 16 : z16;
-                    if (STAGE == STAGE_CB8_GATED) p2 = ok ? gt + cb * plane_b + pix * 16 : z16;
-                }
-            } else if (u < G::IN_UNITS + G::DZ_UNITS) {
-                const int d = u - G::IN_UNITS;
-                const int cb = d / (G::TH * 32);
-                const int r = d - cb * (G::TH * 32);
-                const int gy = y0 + (r >> 5), gx = x0 + (r & 31);
-                const bool ok = (cb < a.mcb_valid) & (gy < H) & (gx < W);
-                const long long off = (((long long)cb * H + gy) * W + gx) * 16;
-                p1 = ok ? dzp + off : z16;
-                if (HAS2) p2 = (ok & has_mask) ? mkp + off : o16;
-            }
-            pf[k] = plc_gload16(p1);
-            if constexpr (HAS2) pf2[k] = plc_gload16(p2);
-            if constexpr (STAGE == STAGE_COORD) {
-                if (k < NPF_IN) {
-                    pf_rain[k] = plc_gload4(pr);
-                    pf_row[k] = plc_gload4(prow);
-                    pf_col[k] = plc_gload4(pcol);
-                }
+                const int cb = second ? NCB0 + cbl : cbl;                       // channel block of the conv input
+                const bool exists = v < (second ? IN1 : IN0);
+                const bool present = exists && (a.in.g_ncb0 == 0 || cb < a.in.g_ncb0);
+                poff[k] = STAGE == STAGE_COORD ? (unsigned)(ly * W + lx) * 4u
+                                               : (unsigned)cbl * plane_b + (unsigned)(ly * W + lx) * 16u;
+                pyx[k] = (unsigned)ly | (unsigned)lx << 8;
+                m_load[k] = __builtin_amdgcn_ballot_w64(present);
+                m_copy[k] = __builtin_amdgcn_ballot_w64(exists && ly < 2 * G::PAD);
+            } else {
+                const int v = tid + 512 * (k - SI);
+                const int cb = v >> ROWS_LOG, r = v & (G::TH * 32 - 1);
+                poff[k] = (unsigned)cb * plane_b + (unsigned)((r >> 5) * W + (r & 31)) * 16u;
+                m_load[k] = __builtin_amdgcn_ballot_w64(v < G::DZ_UNITS && cb < a.mcb_valid);
             }
         }
+    }
+    // Segment s = (image n, segment row sy, strip tx), tx fastest; its tiles j = 0 .. len-1 run downwards.
+    // A tile other than a segment's first shares its input rows 0 .. 2*PAD-1 with rows TH .. of the tile
+    // before it, i.e. of the buffer being contracted while it is loaded.
+    const int seg_tiles = a.seg_tiles;
+    const int segs_y = (a.in.tiles_y + seg_tiles - 1) / seg_tiles;
+    const int n_segs = a.n_tiles;                       // (number of segments)
+    const bool has_mask = HAS2 && a.dz_mask.p != nullptr;
+    // tile_setup fixes the wave-uniform part of a tile's addresses, load_slot(k) requests slot k.  (Measured:
+    // the eight waves queue their loads at the memory pipeline's input for ~1 us per tile after each
+    // barrier, whatever the loader costs in instructions; requesting the slots one by one from inside the
+    // MFMA loop instead stalls the waves there and was 35 % slower.)
+    const char *tb0 = nullptr, *tb1 = nullptr, *tbg = nullptr, *tbd = nullptr, *tbm = nullptr;
+    bool t_skip0 = false, t_skip1 = false, t_inner_in = false, t_inner_dz = false, t_share = false;
+    int t_x0 = 0, t_y0 = 0;
+    // (n, x0, y0: the tile's image and origin; share: its first 2*PAD input rows come from the tile above)
+    auto tile_setup = [&](int n, int x0, int y0, bool share) {
+        const long long org_in = ((long long)(y0 - G::PAD) * W + (x0 - G::PAD)) * (STAGE == STAGE_COORD ? 4 : 16);
+        const long long org_dz = ((long long)y0 * W + x0) * 16;
+        tb0 = plc_img(a.in.src0, n, a.in.n_in) + org_in;
+        tb1 = NCB1 > 0 ? plc_img(a.in.src1, n, a.in.n_in) + org_in : nullptr;
+        tbg = STAGE == STAGE_CB8_GATED ? plc_img(a.in.gate, n, a.in.n_in) + org_in : nullptr;
+        tbd = plc_img(a.dz, n, a.in.n_in) + org_dz;
+        tbm = has_mask ? plc_img(a.dz_mask, n, a.in.n_in) + org_dz : nullptr;
+        // zero_state: src1 (1) or both sources (2) of the first n_in images are the unstored zero initial state
+        t_skip0 = a.in.zero_state == 2 && n < a.in.n_in;
+        t_skip1 = a.in.zero_state != 0 && n < a.in.n_in;
+        t_inner_in = y0 >= G::PAD && y0 + G::TH + G::PAD <= H && x0 >= G::PAD && x0 + 32 + G::PAD <= W;
+        t_inner_dz = y0 + G::TH <= H && x0 + 32 <= W;
+        t_share = share;
+        t_x0 = x0;
+        t_y0 = y0;
     };
-    auto store_tile = [&](int buf) {
+    auto load_slot = [&](int k) {
+        if (k < SI) {
+            const bool second = k >= S0;
+            unsigned long long m = t_share ? m_load[k] & ~m_copy[k] : m_load[k];
+            bool ok = __builtin_amdgcn_inverse_ballot_w64(m);
+            const int gy = t_y0 - G::PAD + (int)(pyx[k] & 255u), gx = t_x0 - G::PAD + (int)(pyx[k] >> 8);
+            if (!t_inner_in || STAGE == STAGE_COORD) ok = ok & ((unsigned)gy < (unsigned)H) & ((unsigned)gx < (unsigned)W);
+            if constexpr (STAGE == STAGE_COORD) {
+                pf_rain[k] = plc_gload4(ok ? tb0 + poff[k] : z16);
+                pf_row[k] = plc_gload4(ok ? (const char*)(a.in.row_tab + gy) : z16);
+                pf_col[k] = plc_gload4(ok ? (const char*)(a.in.col_tab + gx) : z16);
+            } else {
+                const bool skip = second ? t_skip1 : t_skip0;
+                const char* const base = second ? tb1 : tb0;
+                pf[k] = plc_gload16((ok & !skip) ? base + poff[k] : z16);
+                if constexpr (STAGE == STAGE_CB8_GATED) pf2[k] = plc_gload16(ok ? tbg + poff[k] : z16);
+            }
+        } else {
+            const int v = tid + 512 * (k - SI);
+            bool ok = __builtin_amdgcn_inverse_ballot_w64(m_load[k]);
+            if (!t_inner_dz) {
+                const int r = v & (G::TH * 32 - 1);
+                ok = ok & (t_y0 + (r >> 5) < H) & (t_x0 + (r & 31) < W);
+            }
+            pf[k] = plc_gload16(ok ? tbd + poff[k] : z16);
+            if constexpr (HAS2) pf2[k] = plc_gload16((ok & has_mask) ? tbm + poff[k] : o16);
+        }
+    };
+    auto load_tile = [&](int n, int x0, int y0, bool share) {       // (the first tile: everything at once)
+        tile_setup(n, x0, y0, share);
 #pragma unroll
-        for (int k = 0; k < G::NPF; ++k) {
-            const int u = tid + k * 512;
+        for (int k = 0; k < NPF; ++k) load_slot(k);
+    };
+    auto store_tile = [&](int buf, bool share) {
+#pragma unroll
+        for (int k = 0; k < NPF; ++k) {
             uint4 v = pf[k];
-            if constexpr (STAGE == STAGE_CB8_GATED) {
-                if (u < G::IN_UNITS) {
+            if (k < SI) {
+                const bool second = k >= S0;
+                const int u = tid + 512 * (second ? k - S0 : k);
+                const int unit = second ? IN0 + u : u;                          // LDS unit inside the buffer
+                if constexpr (STAGE == STAGE_CB8_GATED) {
                     // src0 * gate, rounded to bf16 (the conv's own gated staging forms the same product)
                     const uint4 f = pf[k], g = pf2[k];
                     const float4 f0 = unpack_bf4(make_uint2(f.x, f.y)), f1 = unpack_bf4(make_uint2(f.z, f.w));
@@ -236,13 +288,15 @@ __global__ __launch_bounds__(512, (plc_wgrad_min_waves<NCB0 + NCB1, MT, KS>())) 
                     const uint2 hi = pack_bf4(f1.x * g1.x, f1.y * g1.y, f1.z * g1.z, f1.w * g1.w);
                     v = make_uint4(lo.x, lo.y, hi.x, hi.y);
                 }
-            }
-            if constexpr (STAGE == STAGE_COORD) {
-                if (k < NPF_IN && u < G::IN_UNITS)      // channels (rain, row coordinate, column coordinate, 0 ...)
+                if constexpr (STAGE == STAGE_COORD)       // channels (rain, row coordinate, column coordinate, 0 ...)
                     v = make_uint4(pack_bf2(pf_rain[k], pf_row[k]), pack_bf2(pf_col[k], 0.0f), 0u, 0u);
-            }
-            if constexpr (HAS2) {
-                if (u >= G::IN_UNITS) {
+                // the staged unit TH rows further down in the buffer being contracted
+                if (share && __builtin_amdgcn_inverse_ballot_w64(m_copy[k])) v = smem[(buf ^ 1) * G::BUF_UNITS + unit + G::TH * G::LW];
+                if (512 * ((second ? k - S0 : k) + 1) <= (second ? IN1 : IN0) || u < (second ? IN1 : IN0))
+                    smem[buf * G::BUF_UNITS + unit] = v;
+            } else {
+                const int u = tid + 512 * (k - SI);
+                if constexpr (HAS2) {
                     // dz counts where mask > 0;  bf16 > 0  <=>  sign bit clear and the other 15 bits not all zero
                     auto keep = [](unsigned m) {
                         const unsigned lo = (m & 0x8000u) == 0 && (m & 0x7fffu) != 0 ? 0x0000ffffu : 0u;
@@ -252,25 +306,51 @@ __global__ __launch_bounds__(512, (plc_wgrad_min_waves<NCB0 + NCB1, MT, KS>())) 
                     const uint4 mk = pf2[k];
                     v.x &= keep(mk.x); v.y &= keep(mk.y); v.z &= keep(mk.z); v.w &= keep(mk.w);
                 }
+                // each dz channel block is padded to DZ_CB units
+                const int unit = G::IN_UNITS + (u >> ROWS_LOG) * G::DZ_CB + (u & (G::TH * 32 - 1));
+                if (512 * (k - SI + 1) <= G::DZ_UNITS || u < G::DZ_UNITS) smem[buf * G::BUF_UNITS + unit] = v;
             }
-            // input part at its unit index; dz part with each channel block padded to DZ_CB units
-            const int dst = u < G::IN_UNITS ? u : u + (u - G::IN_UNITS) / (G::TH * 32) * (G::DZ_CB - G::TH * 32);
-            if (u < G::IN_UNITS + G::DZ_UNITS) smem[buf * G::BUF_UNITS + dst] = v;
         }
     };
 
-    int t = blockIdx.x;
+    // the workgroup's position: segment, tile inside it, and what they decode to
+    auto seg_len = [&](int sy) {
+        const int left = a.in.tiles_y - sy * seg_tiles;
+        return left < seg_tiles ? left : seg_tiles;
+    };
+    PLC_RT_DECL();
+    int seg = blockIdx.x, j = 0;
+    int tn_ = 0, tx_ = 0, sy_ = 0, len = 0;             // image, strip, segment row and length of `seg`
+    auto decode = [&](int s, int& n, int& tx, int& sy) {
+        tx = s % a.in.tiles_x;
+        const int rem = s / a.in.tiles_x;
+        sy = rem % segs_y;
+        n = rem / segs_y;
+    };
     int buf = 0;
-    if (t < a.n_tiles) {
-        load_tile(t);
-        store_tile(0);
+    if (seg < n_segs) {
+        decode(seg, tn_, tx_, sy_);
+        len = seg_len(sy_);
+        load_tile(tn_, tx_ * 32, sy_ * seg_tiles * G::TH, false);
+        store_tile(0, false);
     }
     __syncthreads();
     PLC_AS3 char* lds = (PLC_AS3 char*)smem;
-
-    for (; t < a.n_tiles; t += gridDim.x) {
-        const int tn = t + gridDim.x;
-        if (tn < a.n_tiles) load_tile(tn);            // next tile's loads fly during the MFMAs below
+    PLC_RT(1);                                        // first tile
+    while (seg < n_segs) {
+        // the tile after this one: the next of the segment, or the first of this workgroup's next segment
+        int nseg = seg, nj = j + 1;
+        if (nj == len) {
+            nseg = seg + gridDim.x;
+            nj = 0;
+            if (nseg < n_segs) {
+                decode(nseg, tn_, tx_, sy_);
+                len = seg_len(sy_);
+            }
+        }
+        const bool has_next = nseg < n_segs;
+        if (has_next) load_tile(tn_, tx_ * 32, (sy_ * seg_tiles + nj) * G::TH, G::PAD > 0 && nj > 0);   // flies during the MFMAs below
+        PLC_RT(2);                                    // next tile's loads requested
         const int boff = buf * G::BUF_UNITS * 16;
         // The tile's MFMAs as one flat software pipeline: MFMA j = (k-step j / NT_W, column tile
         // j % NT_W).  Its B fragment is requested DEPTH MFMAs earlier (ring of DEPTH + 1 fragments), its
@@ -318,11 +398,21 @@ __global__ __launch_bounds__(512, (plc_wgrad_min_waves<NCB0 + NCB1, MT, KS>())) 
                                                                      acc[i], 0, 0, 0);
             }
         }
-        if (tn < a.n_tiles) store_tile(buf ^ 1);
+        PLC_RT(3);                                    // MFMA loop
+#ifdef PLC_TIMELINE
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        PLC_RT(4);                                    // wait for the next tile's loads
+#endif
+        if (has_next) store_tile(buf ^ 1, G::PAD > 0 && nj > 0);
+        PLC_RT(5);                                    // registers -> LDS
         __syncthreads();
+        PLC_RT(6);                                    // barrier
         buf ^= 1;
+        seg = nseg;
+        j = nj;
     }
 
+    PLC_RT_FLUSH(778);
     // ---- partial dW of this workgroup -> its slab ---------------------------------------------
     float* slab = a.slab + (long long)blockIdx.x * (MT * 32) * (G::NT * 32);
     const int half = lane >> 5, col = lane & 31;
