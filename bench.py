@@ -236,6 +236,8 @@ def main():
                     help="train mode, one GPU: capture the step into a HIP graph and replay it (pays on launch-bound "
                          "shapes such as c0 / p2 / c1; the large configs are GPU-bound either way)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--shape", default=None, help="B,T,H,W,scale in place of the named configuration's (measurement aid: "
+                                                  "the line then describes that shape, not a BASELINE configuration)")
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
@@ -281,6 +283,9 @@ def main():
     from pl_convlstm_gan_amd.training import train_step
 
     B, T, H, W, s = CONFIGS[args.config]
+    if args.shape:
+        B, T, H, W, s = (int(v) for v in args.shape.split(","))
+        args.config = "custom"
     scaling = "weak"
     if args.global_batch:
         if args.global_batch % world:
