@@ -292,18 +292,13 @@ static bool plc_no_rolling() {
 // The rolling-window kernel (plc_convr_kernel.h): the image is cut into 32-column strips and each strip
 // into segments of seg_rows rows, one workgroup per segment, as many segments as workgroups stay
 // resident (a single round) when the image is large enough for that.
-template <int NCB, int NMT, int STAGE, int EPI, int KSPLIT, bool PLAIN = false>
-static int launch_convr(ConvArgs a, int n_img, int n_mgroups, hipStream_t st) {
+// Segment geometry of a rolling-window launch into `a`; returns its grid size, or an error code (negative).
+template <int NCB, int NMT, int STAGE, int EPI, int KSPLIT, bool PLAIN>
+static int convr_geometry(ConvArgs& a, int n_img, int n_mgroups) {
     using R = PlcRoll<NCB, NMT, KSPLIT>;
     constexpr int lds = plc_convr_lds_bytes<NCB, NMT, KSPLIT, STAGE>();
-    auto kern = plc_convr_kernel<NCB, NMT, STAGE, EPI, KSPLIT, PLAIN>;
     if (PLAIN && (EPI != EPI_ACT_CB8 || a.out1.p || a.mul.p || a.act == ACT_SIGMOID))
         return plc_fail(PLC_EINVAL, "conv: plain epilogue requested with a second output, multiplier or sigmoid");
-    if (lds > 65536) {
-        static bool lds_raised[64] = {false};
-        int rc = ensure_lds_limit((const void*)kern, lds, lds_raised);
-        if (rc) return rc;
-    }
     // (the kernel addresses a lane's unit of an input row with a 32-bit offset from the row's base)
     if ((long long)NCB * a.H * a.W * 16 >= (1ll << 32)) return plc_fail(PLC_EINVAL, "conv: image too large for the rolling-window kernel");
     constexpr int by_lds = (160 * 1024) / lds;
@@ -319,7 +314,21 @@ static int launch_convr(ConvArgs a, int n_img, int n_mgroups, hipStream_t st) {
     if (segs <= 0 || segs >= (1ll << 31)) return plc_fail(PLC_EINVAL, "conv: bad segment count %lld", segs);
     a.n_tiles = (int)segs;
     a.n_blocks = segs < resident ? (int)segs : resident;
-    hipLaunchKernelGGL(kern, dim3(a.n_blocks, n_mgroups), dim3(256), lds, st, a);
+    return a.n_blocks;
+}
+
+template <int NCB, int NMT, int STAGE, int EPI, int KSPLIT, bool PLAIN = false>
+static int launch_convr(ConvArgs a, int n_img, int n_mgroups, hipStream_t st) {
+    constexpr int lds = plc_convr_lds_bytes<NCB, NMT, KSPLIT, STAGE>();
+    auto kern = plc_convr_kernel<NCB, NMT, STAGE, EPI, KSPLIT, PLAIN>;
+    if (lds > 65536) {
+        static bool lds_raised[64] = {false};
+        int rc = ensure_lds_limit((const void*)kern, lds, lds_raised);
+        if (rc) return rc;
+    }
+    const int grid = convr_geometry<NCB, NMT, STAGE, EPI, KSPLIT, PLAIN>(a, n_img, n_mgroups);
+    if (grid < 0) return grid;
+    hipLaunchKernelGGL(kern, dim3(grid, n_mgroups), dim3(256), lds, st, a);
     PLC_HIP(hipGetLastError());
     return PLC_OK;
 }

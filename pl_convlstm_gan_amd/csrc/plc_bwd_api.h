@@ -209,9 +209,9 @@ static Cb8View view(const void* p, long long img) {
     return v;
 }
 
-static int lstm_pointwise_bwd(Cb8View dh0, Cb8View dh1, Cb8View dh2, const void* dc_in, const void* gates,
-                              const void* c_prev, const void* c_cur, void* dz, void* dc_out, int B, int Ch, int H,
-                              int W, hipStream_t st, Cb8View dh0_mul = Cb8View{nullptr, 0}, int dc_bf16 = 0) {
+static LstmBwdArgs lstm_pointwise_bwd_args(Cb8View dh0, Cb8View dh1, Cb8View dh2, const void* dc_in, const void* gates,
+                                           const void* c_prev, const void* c_cur, void* dz, void* dc_out, int B, int Ch,
+                                           int H, int W, Cb8View dh0_mul = Cb8View{nullptr, 0}, int dc_bf16 = 0) {
     LstmBwdArgs a;
     a.B = B; a.ncb = Ch / 8; a.H = H; a.W = W;
     // (PLC_DC_FP32 in the environment keeps the rollout's dc in fp32: A/B timing and accuracy checks)
@@ -221,15 +221,31 @@ static int lstm_pointwise_bwd(Cb8View dh0, Cb8View dh1, Cb8View dh2, const void*
     a.dc_in = (const char*)dc_in; a.gates = (const char*)gates;
     a.c_prev = (const char*)c_prev; a.c_cur = (const char*)c_cur;
     a.dz = (char*)dz; a.dc_out = (char*)dc_out;
-    const long long total = (long long)B * a.ncb * H * W;
+    return a;
+}
+static int lstm_pointwise_bwd_launch(const LstmBwdArgs& a, hipStream_t st) {
+    const long long total = (long long)a.B * a.ncb * a.H * a.W;
     hipLaunchKernelGGL(plc_lstm_pointwise_bwd_kernel, dim3(ew_grid(total)), dim3(256), 0, st, a);
     PLC_HIP(hipGetLastError());
     return PLC_OK;
 }
+static int lstm_pointwise_bwd_launch_pair(const LstmBwdArgs& first, const LstmBwdArgs& second, hipStream_t st) {
+    const int n1 = ew_grid((long long)first.B * first.ncb * first.H * first.W);
+    const int n2 = ew_grid((long long)second.B * second.ncb * second.H * second.W);
+    hipLaunchKernelGGL(plc_lstm_pointwise_bwd_pair_kernel, dim3(n1 + n2), dim3(256), 0, st, first, second, n1);
+    PLC_HIP(hipGetLastError());
+    return PLC_OK;
+}
+static int lstm_pointwise_bwd(Cb8View dh0, Cb8View dh1, Cb8View dh2, const void* dc_in, const void* gates,
+                              const void* c_prev, const void* c_cur, void* dz, void* dc_out, int B, int Ch, int H,
+                              int W, hipStream_t st, Cb8View dh0_mul = Cb8View{nullptr, 0}, int dc_bf16 = 0) {
+    return lstm_pointwise_bwd_launch(lstm_pointwise_bwd_args(dh0, dh1, dh2, dc_in, gates, c_prev, c_cur, dz, dc_out, B, Ch, H, W,
+                                                             dh0_mul, dc_bf16), st);
+}
 
 // data gradient of a cell's gate conv: dz [B][4Ch/8] -> dcat [B][(Cin+Ch)/8] (bf16 CB8, [x | h] order)
-static int cell_dgrad(const void* dz, const void* wpkT, const float* bpk0, void* dcat, int B, int Cin, int Ch,
-                      int H, int W, hipStream_t st) {
+static ConvArgs cell_dgrad_args(const void* dz, const void* wpkT, const float* bpk0, void* dcat, int B, int Cin, int Ch,
+                                int H, int W) {
     const long long hw = (long long)H * W;
     ConvArgs a = conv_args(H, W, B);
     a.src0 = tens(dz, (4 * Ch / 8) * hw * 16, 0);
@@ -238,6 +254,11 @@ static int cell_dgrad(const void* dz, const void* wpkT, const float* bpk0, void*
     a.bpk = bpk0;
     a.act = ACT_NONE;
     a.ncb_out = (Cin + Ch) / 8;
+    return a;
+}
+static int cell_dgrad(const void* dz, const void* wpkT, const float* bpk0, void* dcat, int B, int Cin, int Ch,
+                      int H, int W, hipStream_t st) {
+    const ConvArgs a = cell_dgrad_args(dz, wpkT, bpk0, dcat, B, Cin, Ch, H, W);
     if (Cin == 16 && Ch == 16)
         return plc_no_rolling() ? launch_conv_th<8, 0, 1, 3, STAGE_CB8, EPI_ACT_CB8, 8, 1>(a, B, 1, st)
                                 : launch_convr<8, 1, STAGE_CB8, EPI_ACT_CB8, 1, true>(a, B, 1, st);
@@ -249,6 +270,26 @@ static int cell_dgrad(const void* dz, const void* wpkT, const float* bpk0, void*
     return plc_fail(PLC_EUNSUPPORTED, "ConvLSTM cell backward (Cin=%d, Ch=%d): channel counts must be multiples of 8", Cin, Ch);
 }
 static int cell_dgrad_ksplit(int Cin, int Ch) { return (Cin == 16 && Ch == 32) ? 2 : 1; }
+
+// The data gradients of cell 2 (16 -> 32 hidden channels, step t - 1) and cell 1 (16 -> 16, step t) in one launch.
+static int cell_dgrad_pair(const ConvArgs& c2, const ConvArgs& c1, int B, hipStream_t st) {
+    constexpr int lds2 = plc_convr_lds_bytes<16, 2, 2, STAGE_CB8>(), lds1 = plc_convr_lds_bytes<8, 1, 1, STAGE_CB8>();
+    constexpr int lds = lds2 > lds1 ? lds2 : lds1;
+    static bool lds_raised[64] = {false};
+    int rc = ensure_lds_limit((const void*)plc_convr_dgrad_pair_kernel, lds, lds_raised);
+    if (rc) return rc;
+    ConvrPairArgs p;
+    p.c2 = c2;
+    p.c1 = c1;
+    const int n2 = convr_geometry<16, 2, STAGE_CB8, EPI_ACT_CB8, 2, true>(p.c2, B, 1);
+    if (n2 < 0) return n2;
+    const int n1 = convr_geometry<8, 1, STAGE_CB8, EPI_ACT_CB8, 1, true>(p.c1, B, 1);
+    if (n1 < 0) return n1;
+    p.n2 = n2;
+    hipLaunchKernelGGL(plc_convr_dgrad_pair_kernel, dim3(n2 + n1), dim3(256), lds, st, p);
+    PLC_HIP(hipGetLastError());
+    return PLC_OK;
+}
 
 // h0_zero: the first n_in images of `h` are the zero initial state and are not read (a rollout
 // does not store them).
@@ -672,35 +713,65 @@ extern "C" int plc_generator_rollout_bwd(const plc_rollout_desc* d, const plc_ro
     const size_t s1 = (size_t)B * fp.img1, s2 = (size_t)B * fp.img2;      // bytes of one step (bf16 CB8)
     const size_t cat1 = (size_t)(2 * C1 / 8) * hw * 16, cat2 = (size_t)((C1 + C2) / 8) * hw * 16;
     const size_t plane = (size_t)hw * 16;
-    for (int t = T - 1; t >= 0; --t) {
+    // Per step t (downwards): pointwise backward of cell 2, its data-gradient conv (-> d[h1_t | h2_{t-1}]), then
+    // the same for cell 1 (-> d[x_t | h1_{t-1}]).  Cell 2 of step t - 1 needs only cell 2's conv of step t, as
+    // cell 1 of step t does, so with the widths the rolling-window convs are built for the loop is skewed:
+    // one launch runs both pointwise passes, the next both convs (2T + 2 launches instead of 4T, and cell 1's
+    // workgroups fill the CUs that cell 2's leave).  Same kernels' bodies, same results.
+    auto pw2_args = [&](int t) {
         const bool last = (t == T - 1);
-        char* dcat2_t = wb + bp.dcat2 + (size_t)(t & 1) * B * cat2;
         const char* dcat2_n = wb + bp.dcat2 + (size_t)((t + 1) & 1) * B * cat2;
-        char* dc2_t = wb + bp.dc2 + (size_t)(t & 1) * s2 * 2;
-        const char* dc2_n = wb + bp.dc2 + (size_t)((t + 1) & 1) * s2 * 2;
-        char* dz2_t = wb + bp.dz2 + (size_t)t * s2 * 4;
-        if ((rc = lstm_pointwise_bwd(view(cur + (size_t)t * s2, fp.img2),
-                                     last ? view(nullptr, 0) : view(dcat2_n + (C1 / 8) * plane, cat2), view(nullptr, 0),
-                                     last ? nullptr : dc2_n, wf + fp.gates2 + (size_t)t * s2 * 4,
-                                     t == 0 ? nullptr : wf + fp.c2s + (size_t)t * s2 * 2,     // c_{-1} = 0 is not stored
-                                     wf + fp.c2s + (size_t)(t + 1) * s2 * 2, dz2_t,
-                                     dc2_t, B, C2, H, W, st,
-                                     direct ? view(wf + fp.gate, fp.img2) : view(nullptr, 0), 1)))
-            return rc;
-        if ((rc = cell_dgrad(dz2_t, wb + bp.cell2T, bpk0, dcat2_t, B, C1, C2, H, W, st))) return rc;
-
-        char* dcat1_t = wb + bp.dcat1 + (size_t)t * B * cat1;
+        return lstm_pointwise_bwd_args(view(cur + (size_t)t * s2, fp.img2),
+                                       last ? view(nullptr, 0) : view(dcat2_n + (C1 / 8) * plane, cat2), view(nullptr, 0),
+                                       last ? nullptr : wb + bp.dc2 + (size_t)((t + 1) & 1) * s2 * 2,
+                                       wf + fp.gates2 + (size_t)t * s2 * 4,
+                                       t == 0 ? nullptr : wf + fp.c2s + (size_t)t * s2 * 2,     // c_{-1} = 0 is not stored
+                                       wf + fp.c2s + (size_t)(t + 1) * s2 * 2, wb + bp.dz2 + (size_t)t * s2 * 4,
+                                       wb + bp.dc2 + (size_t)(t & 1) * s2 * 2, B, C2, H, W,
+                                       direct ? view(wf + fp.gate, fp.img2) : view(nullptr, 0), 1);
+    };
+    auto pw1_args = [&](int t) {
+        const bool last = (t == T - 1);
         const char* dcat1_n = wb + bp.dcat1 + (size_t)(t + 1) * B * cat1;
-        char* dc1_t = wb + bp.dc1 + (size_t)(t & 1) * s1 * 2;
-        const char* dc1_n = wb + bp.dc1 + (size_t)((t + 1) & 1) * s1 * 2;
-        char* dz1_t = wb + bp.dz1 + (size_t)t * s1 * 4;
-        if ((rc = lstm_pointwise_bwd(view(dcat2_t, cat2), last ? view(nullptr, 0) : view(dcat1_n + (C1 / 8) * plane, cat1),
-                                     view(nullptr, 0), last ? nullptr : dc1_n, wf + fp.gates1 + (size_t)t * s1 * 4,
-                                     t == 0 ? nullptr : wf + fp.c1s + (size_t)t * s1 * 2,
-                                     wf + fp.c1s + (size_t)(t + 1) * s1 * 2, dz1_t,
-                                     dc1_t, B, C1, H, W, st, view(nullptr, 0), 1)))
+        return lstm_pointwise_bwd_args(view(wb + bp.dcat2 + (size_t)(t & 1) * B * cat2, cat2),
+                                       last ? view(nullptr, 0) : view(dcat1_n + (C1 / 8) * plane, cat1), view(nullptr, 0),
+                                       last ? nullptr : wb + bp.dc1 + (size_t)((t + 1) & 1) * s1 * 2,
+                                       wf + fp.gates1 + (size_t)t * s1 * 4,
+                                       t == 0 ? nullptr : wf + fp.c1s + (size_t)t * s1 * 2,
+                                       wf + fp.c1s + (size_t)(t + 1) * s1 * 2, wb + bp.dz1 + (size_t)t * s1 * 4,
+                                       wb + bp.dc1 + (size_t)(t & 1) * s1 * 2, B, C1, H, W, view(nullptr, 0), 1);
+    };
+    auto dg2_args = [&](int t) {
+        return cell_dgrad_args(wb + bp.dz2 + (size_t)t * s2 * 4, wb + bp.cell2T, bpk0, wb + bp.dcat2 + (size_t)(t & 1) * B * cat2,
+                               B, C1, C2, H, W);
+    };
+    auto dg1_args = [&](int t) {
+        return cell_dgrad_args(wb + bp.dz1 + (size_t)t * s1 * 4, wb + bp.cell1T, bpk0, wb + bp.dcat1 + (size_t)t * B * cat1,
+                               B, C1, C1, H, W);
+    };
+    const bool skew = fast && T > 1 && !plc_no_rolling() && !plc_no_pairing();
+    if (skew) {
+        if ((rc = lstm_pointwise_bwd_launch(pw2_args(T - 1), st))) return rc;
+        if ((rc = cell_dgrad(wb + bp.dz2 + (size_t)(T - 1) * s2 * 4, wb + bp.cell2T, bpk0,
+                             wb + bp.dcat2 + (size_t)((T - 1) & 1) * B * cat2, B, C1, C2, H, W, st)))
             return rc;
-        if ((rc = cell_dgrad(dz1_t, wb + bp.cell1T, bpk0, dcat1_t, B, C1, C1, H, W, st))) return rc;
+        for (int t = T - 1; t >= 1; --t) {
+            if ((rc = lstm_pointwise_bwd_launch_pair(pw2_args(t - 1), pw1_args(t), st))) return rc;
+            if ((rc = cell_dgrad_pair(dg2_args(t - 1), dg1_args(t), B, st))) return rc;
+        }
+        if ((rc = lstm_pointwise_bwd_launch(pw1_args(0), st))) return rc;
+        if ((rc = cell_dgrad(wb + bp.dz1, wb + bp.cell1T, bpk0, wb + bp.dcat1, B, C1, C1, H, W, st))) return rc;
+    } else {
+        for (int t = T - 1; t >= 0; --t) {
+            if ((rc = lstm_pointwise_bwd_launch(pw2_args(t), st))) return rc;
+            if ((rc = cell_dgrad(wb + bp.dz2 + (size_t)t * s2 * 4, wb + bp.cell2T, bpk0, wb + bp.dcat2 + (size_t)(t & 1) * B * cat2,
+                                 B, C1, C2, H, W, st)))
+                return rc;
+            if ((rc = lstm_pointwise_bwd_launch(pw1_args(t), st))) return rc;
+            if ((rc = cell_dgrad(wb + bp.dz1 + (size_t)t * s1 * 4, wb + bp.cell1T, bpk0, wb + bp.dcat1 + (size_t)t * B * cat1,
+                                 B, C1, C1, H, W, st)))
+                return rc;
+        }
     }
     // ---- stem: weight gradient; the gradient through its ReLU is a mask applied while loading dz ----
     {

@@ -58,11 +58,12 @@ struct LstmBwdArgs {
     char* dc_out;                  // fp32 (or bf16) CB8 [B][ncb]
 };
 
-__global__ void plc_lstm_pointwise_bwd_kernel(const LstmBwdArgs a) {
+// (block, n_blocks: this workgroup's position in the grid-stride loop over the launch's units)
+__device__ __forceinline__ void plc_lstm_pointwise_bwd_body(const LstmBwdArgs& a, int block, int n_blocks) {
     const long long hw = (long long)a.H * a.W;
     const long long total = (long long)a.B * a.ncb * hw;
-    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
-         idx += (long long)gridDim.x * blockDim.x) {
+    for (long long idx = block * (long long)blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)n_blocks * blockDim.x) {
         const long long pix = idx % hw;
         const int cb = (idx / hw) % a.ncb;
         const long long b = idx / (hw * a.ncb);
@@ -125,6 +126,17 @@ __global__ void plc_lstm_pointwise_bwd_kernel(const LstmBwdArgs a) {
         if (a.dc_bf16) st_bf8(a.dc_out + su * 16, dcp);
         else st_f8(a.dc_out + su * 32, dcp);
     }
+}
+
+__global__ void plc_lstm_pointwise_bwd_kernel(const LstmBwdArgs a) {
+    plc_lstm_pointwise_bwd_body(a, blockIdx.x, gridDim.x);
+}
+
+// Two independent pointwise backward passes in one launch (cell 2 of step t - 1 and cell 1 of step t both
+// wait for the same data-gradient conv and for nothing else): workgroups [0, n_first) take `first`.
+__global__ void plc_lstm_pointwise_bwd_pair_kernel(const LstmBwdArgs first, const LstmBwdArgs second, int n_first) {
+    if ((int)blockIdx.x < n_first) plc_lstm_pointwise_bwd_body(first, blockIdx.x, n_first);
+    else plc_lstm_pointwise_bwd_body(second, blockIdx.x - n_first, gridDim.x - n_first);
 }
 
 // Gating backward, once per call, over (b, channel block, pixel); loops over the T frames:

@@ -180,8 +180,11 @@ __device__ __forceinline__ void plc_roll_store_row(const ConvArgs& a, const f32x
 // ConvArgs: n_tiles = number of segments, n_blocks = gridDim.x (workgroup b takes segments b, b + n_blocks,
 // ...), tiles_y = segments per 32-column strip, tiles_x = strips per image, seg_rows = rows per segment
 // (a multiple of A).  PLAIN: see plc_epilogue.
+// block_x / block_y / n_mgroups: the workgroup's position (as blockIdx.x, blockIdx.y, gridDim.y of a launch
+// of its own); lds: its dynamic LDS.
 template <int NCB, int NMT, int STAGE, int EPI, int KSPLIT, bool PLAIN>
-__global__ __launch_bounds__(256, 2) void plc_convr_kernel(const ConvArgs a) {
+__device__ __forceinline__ void plc_convr_body(const ConvArgs& a, const int block_x, const int block_y, const int n_mgroups,
+                                               uint4* const plc_convr_lds) {
     using R = PlcRoll<NCB, NMT, KSPLIT>;
     constexpr int NCBW = R::NCBW, NCBP = R::NCBP, NKS = R::NKS, NREP = R::NREP, A = R::A, RING = R::RING, LW = R::LW;
     constexpr int ROWB = R::ROW_UNITS * 16;
@@ -190,7 +193,6 @@ __global__ __launch_bounds__(256, 2) void plc_convr_kernel(const ConvArgs a) {
     static_assert(EPI != EPI_LSTM && EPI != EPI_LSTM_SAVE, "the ConvLSTM cells use plc_conv_kernel.h");
     static_assert(NCB % KSPLIT == 0 && NCBW % 2 == 0, "each wave contracts an even number of channel blocks");
     static_assert(NMT * KSPLIT == 1 || NMT * KSPLIT == 2 || NMT * KSPLIT == 4, "NMT*KSPLIT must be 1, 2 or 4");
-    extern __shared__ __attribute__((aligned(16))) uint4 plc_convr_lds[];
     uint4* const ring = plc_convr_lds;
     float4* const red = (float4*)(ring + R::RING_UNITS);
     uint4* const gstage = ring + R::RING_UNITS + R::RED_UNITS;
@@ -198,7 +200,7 @@ __global__ __launch_bounds__(256, 2) void plc_convr_kernel(const ConvArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, px = lane & 31;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     const int m = wave_u % NMT, ks = (wave_u / NMT) % KSPLIT, rg = wave_u / (NMT * KSPLIT);
-    const int mt = blockIdx.y * NMT + m, n_mt = gridDim.y * NMT;
+    const int mt = block_y * NMT + m, n_mt = n_mgroups * NMT;
     const int H = a.H, W = a.W;
 
     // (asm loads: the compiler keeps no count of them, so it does not drain the row requests that follow
@@ -221,7 +223,7 @@ __global__ __launch_bounds__(256, 2) void plc_convr_kernel(const ConvArgs a) {
                             (unsigned)(((ks * NCBW + half) * LW + px) * 16);
 
     PLC_RT_DECL();
-    const int bx = (int)blockIdx.x;
+    const int bx = block_x;
 #pragma unroll 1
     for (int seg = bx; seg < a.n_tiles; seg += a.n_blocks) {
         const int sy = seg % a.tiles_y;
@@ -383,4 +385,23 @@ __global__ __launch_bounds__(256, 2) void plc_convr_kernel(const ConvArgs a) {
 #undef PLC_ROLL_EPI
     }
     PLC_RT_FLUSH(777);
+}
+
+template <int NCB, int NMT, int STAGE, int EPI, int KSPLIT, bool PLAIN>
+__global__ __launch_bounds__(256, 2) void plc_convr_kernel(const ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint4 plc_convr_smem[];
+    plc_convr_body<NCB, NMT, STAGE, EPI, KSPLIT, PLAIN>(a, blockIdx.x, blockIdx.y, gridDim.y, plc_convr_smem);
+}
+
+// The two data-gradient convs of one backward step of the two-cell recurrence that do not depend on each
+// other (cell 2 of step t - 1 and cell 1 of step t) in ONE launch, cell 2's workgroups first: cell 1's
+// segments start on the CUs that cell 2's workgroups leave, instead of after the whole grid has drained.
+struct ConvrPairArgs {
+    ConvArgs c2, c1;
+    int n2;              // workgroups [0, n2) run c2
+};
+__global__ __launch_bounds__(256, 2) void plc_convr_dgrad_pair_kernel(const ConvrPairArgs p) {
+    extern __shared__ __attribute__((aligned(16))) uint4 plc_convr_smem[];
+    if ((int)blockIdx.x < p.n2) plc_convr_body<16, 2, STAGE_CB8, EPI_ACT_CB8, 2, true>(p.c2, blockIdx.x, 0, 1, plc_convr_smem);
+    else plc_convr_body<8, 1, STAGE_CB8, EPI_ACT_CB8, 1, true>(p.c1, blockIdx.x - p.n2, 0, 1, plc_convr_smem);
 }
