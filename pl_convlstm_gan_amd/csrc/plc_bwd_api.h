@@ -291,6 +291,51 @@ static int cell_dgrad_pair(const ConvArgs& c2, const ConvArgs& c1, int B, hipStr
     return PLC_OK;
 }
 
+// The same convs in their PW form (plc_convr_kernel.h): the cell's pointwise backward runs inside the conv, which
+// forms its input dz row by row instead of reading it.  `pw` as for lstm_pointwise_bwd_launch, `c` as for cell_dgrad.
+// (Off unless PLC_FUSED_PW=1: measured slower than the separate pass, see plc_convr_kernel.h.)
+static bool plc_fused_pw() {
+    static const bool on = [] { const char* e = getenv("PLC_FUSED_PW"); return e && *e && *e != '0'; }();
+    return on;
+}
+template <int NCB, int NMT, int KSPLIT>
+static int cell_dgrad_pw(const LstmBwdArgs& pw, const ConvArgs& c, int B, hipStream_t st) {
+    constexpr int lds = plc_convr_lds_bytes<NCB, NMT, KSPLIT, STAGE_CB8>();
+    auto kern = plc_convr_pw_kernel<NCB, NMT, KSPLIT>;
+    static bool lds_raised[64] = {false};
+    int rc = ensure_lds_limit((const void*)kern, lds, lds_raised);
+    if (rc) return rc;
+    ConvrPwArgs p;
+    p.c = c;
+    p.pw = pw;
+    const int grid = convr_geometry<NCB, NMT, STAGE_CB8, EPI_ACT_CB8, KSPLIT, true>(p.c, B, 1);
+    if (grid < 0) return grid;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, p);
+    PLC_HIP(hipGetLastError());
+    return PLC_OK;
+}
+static int cell_dgrad_pw_pair(const LstmBwdArgs& pw2, const ConvArgs& c2, const LstmBwdArgs& pw1, const ConvArgs& c1, int B,
+                              hipStream_t st) {
+    constexpr int lds2 = plc_convr_lds_bytes<16, 2, 2, STAGE_CB8>(), lds1 = plc_convr_lds_bytes<8, 1, 1, STAGE_CB8>();
+    constexpr int lds = lds2 > lds1 ? lds2 : lds1;
+    static bool lds_raised[64] = {false};
+    int rc = ensure_lds_limit((const void*)plc_convr_pw_pair_kernel, lds, lds_raised);
+    if (rc) return rc;
+    ConvrPwPairArgs p;
+    p.c2.c = c2;
+    p.c2.pw = pw2;
+    p.c1.c = c1;
+    p.c1.pw = pw1;
+    const int n2 = convr_geometry<16, 2, STAGE_CB8, EPI_ACT_CB8, 2, true>(p.c2.c, B, 1);
+    if (n2 < 0) return n2;
+    const int n1 = convr_geometry<8, 1, STAGE_CB8, EPI_ACT_CB8, 1, true>(p.c1.c, B, 1);
+    if (n1 < 0) return n1;
+    p.n2 = n2;
+    hipLaunchKernelGGL(plc_convr_pw_pair_kernel, dim3(n2 + n1), dim3(256), lds, st, p);
+    PLC_HIP(hipGetLastError());
+    return PLC_OK;
+}
+
 // h0_zero: the first n_in images of `h` are the zero initial state and are not read (a rollout
 // does not store them).
 static int cell_wgrad(const void* dz, PlcTensor x, PlcTensor h, int n_in, int n_img, SlabArena* slab,
@@ -750,7 +795,13 @@ extern "C" int plc_generator_rollout_bwd(const plc_rollout_desc* d, const plc_ro
                                B, C1, C1, H, W);
     };
     const bool skew = fast && T > 1 && !plc_no_rolling() && !plc_no_pairing();
-    if (skew) {
+    if (skew && plc_fused_pw()) {
+        // T + 1 launches: each conv forms its own input (the pointwise pass runs inside it)
+        if ((rc = cell_dgrad_pw<16, 2, 2>(pw2_args(T - 1), dg2_args(T - 1), B, st))) return rc;
+        for (int t = T - 1; t >= 1; --t)
+            if ((rc = cell_dgrad_pw_pair(pw2_args(t - 1), dg2_args(t - 1), pw1_args(t), dg1_args(t), B, st))) return rc;
+        if ((rc = cell_dgrad_pw<8, 1, 1>(pw1_args(0), dg1_args(0), B, st))) return rc;
+    } else if (skew) {
         if ((rc = lstm_pointwise_bwd_launch(pw2_args(T - 1), st))) return rc;
         if ((rc = cell_dgrad(wb + bp.dz2 + (size_t)(T - 1) * s2 * 4, wb + bp.cell2T, bpk0,
                              wb + bp.dcat2 + (size_t)((T - 1) & 1) * B * cat2, B, C1, C2, H, W, st)))

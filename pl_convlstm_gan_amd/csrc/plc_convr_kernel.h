@@ -15,8 +15,21 @@
 // reads of the MFMA loop are inline asm with hand-placed lgkmcnt waits (LDS reads return in order);
 // the remaining LDS accesses of a pass (partial-sum exchange, gate product) sit behind the pass's own
 // wait for the rows in flight.
+//
+// PW form (the ConvLSTM cells' data gradients inside a rollout's backward): the input rows are not fetched
+// but FORMED -- the conv's input dz is the output of the cell's pointwise backward (plc_lstm_bwd_unit.h),
+// so the workgroup computes each row group of its window from the saved gates, c_{t-1}, dL/dc and the
+// incoming dL/dh, writes it into the ring, and stores the pixels it owns (dz for the batched weight
+// gradient, dL/dc for the next step) to memory.  The standalone pointwise pass disappears: dz is written
+// once and never read back by this step, at the price of recomputing the halo pixels (x 1.2).  It produces
+// the same bits and moves 16 % fewer bytes, and it is SLOWER than the two kernels it replaces (cell 2 at
+// 256 x 256, B = 4: 100 us against 46 + 37): the pass's loads and its ~2000 vector-ALU cycles per unit
+// run between the MFMA phases of a kernel with eight waves per CU instead of under twenty waves'
+// worth of memory latency, and the 16 halo-column units of a row group cost a second full iteration.
+// The rollout therefore uses it only when PLC_FUSED_PW=1 is set.
 #pragma once
 #include "plc_conv_kernel.h"
+#include "plc_lstm_bwd_unit.h"
 
 #ifdef PLC_TIMELINE
 // Instrumented build only: per wave, the time spent in each phase of the pass loop, summed over the
@@ -177,19 +190,70 @@ __device__ __forceinline__ void plc_roll_store_row(const ConvArgs& a, const f32x
     }
 }
 
+// PW form: rows y_first .. y_first + count - 1 of the window, computed.  Thread w of the workgroup takes unit
+// (row i, hidden channel block hb, column lx) = (w / (NHB * 34), (w / 34) % NHB, w % 34): 34 consecutive
+// threads read 544 consecutive bytes of every input tensor.  Pixels outside the image are the conv's zero
+// padding.  A pixel is OWNED (its dz / dL/dc go to memory) by the segment whose output rows [ya, yb) and
+// columns x0 .. x0 + 31 contain it; halo pixels are computed again by the neighbouring segments.
+template <int NCB, int NMT, int KSPLIT>
+__device__ __forceinline__ void plc_roll_stage_pw(const LstmBwdArgs& pw, uint4* ring, int tid, int n, int x0, int y_first,
+                                                  int count, int slot0, int ya, int yb) {
+    using R = PlcRoll<NCB, NMT, KSPLIT>;
+    constexpr int NHB = NCB / 4;
+    static_assert(NCB % 4 == 0, "dz has four gate blocks per hidden channel block");
+    const int H = pw.H, W = pw.W;
+    const long long hw = (long long)H * W;
+    const int total = count * NHB * R::LW;
+#pragma unroll 1
+    for (int w = tid; w < total; w += 256) {
+        const int lx = w % R::LW, q = w / R::LW;
+        const int hb = q % NHB, i = q / NHB;
+        int slot = slot0 + i;
+        if (slot >= R::RING) slot -= R::RING;
+        const int gy = y_first + i, gx = x0 - 1 + lx;
+        const bool in_img = (gy >= 0) & (gy < H) & (gx >= 0) & (gx < W);
+        F8 zi, zf, zo, zg, dcp;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) zi.v[j] = zf.v[j] = zo.v[j] = zg.v[j] = dcp.v[j] = 0.0f;
+        const long long u = hb * hw + (long long)gy * W + gx;
+        if (in_img) plc_lstm_bwd_unit(pw, n, u, zi, zf, zo, zg, dcp);
+        const uint4 pi = make_uint4(pack_bf2(zi.v[0], zi.v[1]), pack_bf2(zi.v[2], zi.v[3]), pack_bf2(zi.v[4], zi.v[5]), pack_bf2(zi.v[6], zi.v[7]));
+        const uint4 pf = make_uint4(pack_bf2(zf.v[0], zf.v[1]), pack_bf2(zf.v[2], zf.v[3]), pack_bf2(zf.v[4], zf.v[5]), pack_bf2(zf.v[6], zf.v[7]));
+        const uint4 po = make_uint4(pack_bf2(zo.v[0], zo.v[1]), pack_bf2(zo.v[2], zo.v[3]), pack_bf2(zo.v[4], zo.v[5]), pack_bf2(zo.v[6], zo.v[7]));
+        const uint4 pg = make_uint4(pack_bf2(zg.v[0], zg.v[1]), pack_bf2(zg.v[2], zg.v[3]), pack_bf2(zg.v[4], zg.v[5]), pack_bf2(zg.v[6], zg.v[7]));
+        uint4* const r = ring + (slot * NCB + hb) * R::LW + lx;       // gate-major channel blocks: block = gate * NHB + hb
+        r[0 * NHB * R::LW] = pi;
+        r[1 * NHB * R::LW] = pf;
+        r[2 * NHB * R::LW] = po;
+        r[3 * NHB * R::LW] = pg;
+        if (in_img & (lx >= 1) & (lx <= 32) & (gy >= ya) & (gy < yb)) {
+            const long long su = ((long long)n * pw.ncb) * hw + u;          // unit index in [B][ncb] tensors
+            const long long gu = ((long long)n * 4 * pw.ncb) * hw + u;      // unit index of gate 0 in [B][4 ncb]
+            *(uint4*)(pw.dz + (gu + 0 * pw.ncb * hw) * 16) = pi;
+            *(uint4*)(pw.dz + (gu + 1 * pw.ncb * hw) * 16) = pf;
+            *(uint4*)(pw.dz + (gu + 2 * pw.ncb * hw) * 16) = po;
+            *(uint4*)(pw.dz + (gu + 3 * pw.ncb * hw) * 16) = pg;
+            if (pw.dc_bf16) st_bf8(pw.dc_out + su * 16, dcp);
+            else st_f8(pw.dc_out + su * 32, dcp);
+        }
+    }
+}
+
 // ConvArgs: n_tiles = number of segments, n_blocks = gridDim.x (workgroup b takes segments b, b + n_blocks,
 // ...), tiles_y = segments per 32-column strip, tiles_x = strips per image, seg_rows = rows per segment
 // (a multiple of A).  PLAIN: see plc_epilogue.
 // block_x / block_y / n_mgroups: the workgroup's position (as blockIdx.x, blockIdx.y, gridDim.y of a launch
 // of its own); lds: its dynamic LDS.
-template <int NCB, int NMT, int STAGE, int EPI, int KSPLIT, bool PLAIN>
+// PW: the input rows are formed from `pw` (see the head of this file) instead of being fetched from a.src0.
+template <int NCB, int NMT, int STAGE, int EPI, int KSPLIT, bool PLAIN, bool PW = false>
 __device__ __forceinline__ void plc_convr_body(const ConvArgs& a, const int block_x, const int block_y, const int n_mgroups,
-                                               uint4* const plc_convr_lds) {
+                                               uint4* const plc_convr_lds, const LstmBwdArgs* const pw = nullptr) {
     using R = PlcRoll<NCB, NMT, KSPLIT>;
     constexpr int NCBW = R::NCBW, NCBP = R::NCBP, NKS = R::NKS, NREP = R::NREP, A = R::A, RING = R::RING, LW = R::LW;
     constexpr int ROWB = R::ROW_UNITS * 16;
     constexpr bool GATED = STAGE == STAGE_CB8_GATED;
     static_assert(STAGE == STAGE_CB8 || STAGE == STAGE_CB8_GATED, "the rolling conv stages CB8 tensors by LDS-DMA");
+    static_assert(!PW || (STAGE == STAGE_CB8 && PLAIN), "the PW form is the cells' plain data-gradient conv");
     static_assert(EPI != EPI_LSTM && EPI != EPI_LSTM_SAVE, "the ConvLSTM cells use plc_conv_kernel.h");
     static_assert(NCB % KSPLIT == 0 && NCBW % 2 == 0, "each wave contracts an even number of channel blocks");
     static_assert(NMT * KSPLIT == 1 || NMT * KSPLIT == 2 || NMT * KSPLIT == 4, "NMT*KSPLIT must be 1, 2 or 4");
@@ -232,7 +296,7 @@ __device__ __forceinline__ void plc_convr_body(const ConvArgs& a, const int bloc
         const int x0 = tx * 32, ya = sy * a.seg_rows;
         const int yb = ya + a.seg_rows < H ? ya + a.seg_rows : H;
         const int npass = (yb - ya + A - 1) / A;
-        const char* const s0 = plc_img(a.src0, n, a.n_in);
+        const char* const s0 = PW ? nullptr : plc_img(a.src0, n, a.n_in);
         const char* const gt = GATED ? plc_img(a.gate, n, a.n_in) : nullptr;
         PlcRollLane<NCB, NMT, KSPLIT> ln;
         plc_roll_lane_setup<NCB, NMT, KSPLIT>(ln, lane, wave_u, x0, H, W);
@@ -250,13 +314,19 @@ __device__ __forceinline__ void plc_convr_body(const ConvArgs& a, const int bloc
         // every wave has finished with the previous segment's rows (and its partial sums)
         if (seg != bx) plc_lds_barrier();
         // window 0 = rows ya - 1 .. ya + A in slots 0 .. A + 1; the rows pass 1 adds go to slots A + 2 .. 2A + 1
-        PLC_ROLL_ISSUE(ya - 1, A + 2, 0);
-        if constexpr (GATED) {
+        if constexpr (PW) {
+            plc_roll_stage_pw<NCB, NMT, KSPLIT>(*pw, ring, tid, n, x0, ya - 1, A + 2, 0, ya, yb);
+            if (npass > 1) plc_roll_stage_pw<NCB, NMT, KSPLIT>(*pw, ring, tid, n, x0, ya + A + 1, A, A + 2, ya, yb);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the weights' uncounted loads)
+            plc_lds_barrier();
+        } else if constexpr (GATED) {
+            PLC_ROLL_ISSUE(ya - 1, A + 2, 0);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             plc_roll_gate<NCB, NMT, KSPLIT>(ln, ring, gstage, lane, wave_u, A + 2, 0);
             plc_lds_barrier();
             if (npass > 1) PLC_ROLL_ISSUE(ya + A + 1, A, A + 2);
         } else {
+            PLC_ROLL_ISSUE(ya - 1, A + 2, 0);
             int n1 = 0;
             if (npass > 1) n1 = PLC_ROLL_ISSUE(ya + A + 1, A, A + 2);
             plc_wait_vmcnt_le(n1);      // loads retire in order: all but the n1 youngest are window 0
@@ -335,7 +405,7 @@ __device__ __forceinline__ void plc_convr_body(const ConvArgs& a, const int bloc
             }
             PLC_RT(3);                   // exchange barrier + partial-sum writes (incl. the compiler's own wait for the rows in flight)
             // the rows pass p + 1 adds (requested one pass ago) have landed ...
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if constexpr (!PW) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             PLC_RT(4);                   // wait for the rows in flight
             int wn = w + A;
             if (wn >= RING) wn -= RING;
@@ -355,7 +425,9 @@ __device__ __forceinline__ void plc_convr_body(const ConvArgs& a, const int bloc
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 PLC_RT(7);               // partial-sum reads
                 // the rows pass p + 2 adds replace the first A rows of this pass's window
-                if (p + 2 < npass) PLC_ROLL_ISSUE(ya + (p + 2) * A + 1, A, w);
+                if constexpr (!PW) {
+                    if (p + 2 < npass) PLC_ROLL_ISSUE(ya + (p + 2) * A + 1, A, w);
+                }
                 PLC_RT(8);               // next request
                 if (ks == 0) {
 #pragma unroll
@@ -371,12 +443,18 @@ __device__ __forceinline__ void plc_convr_body(const ConvArgs& a, const int bloc
                     PLC_ROLL_EPI(acc[1], row0 + 1);
                 }
             } else {
-                if (p + 2 < npass) PLC_ROLL_ISSUE(ya + (p + 2) * A + 1, A, w);
+                if constexpr (!PW) {
+                    if (p + 2 < npass) PLC_ROLL_ISSUE(ya + (p + 2) * A + 1, A, w);
+                }
 #pragma unroll
                 for (int r = 0; r < NREP; ++r) {
                     PLC_ROLL_EPI(acc[r], row0 + r);
                     __builtin_amdgcn_sched_barrier(0);
                 }
+            }
+            // PW: with this pass's results on their way out (and their registers free), form the rows pass p + 2 adds
+            if constexpr (PW) {
+                if (p + 2 < npass) plc_roll_stage_pw<NCB, NMT, KSPLIT>(*pw, ring, tid, n, x0, ya + (p + 2) * A + 1, A, w, ya, yb);
             }
             w = wn;
             PLC_RT(6);                   // partial-sum reads, next request, epilogue
@@ -391,6 +469,28 @@ template <int NCB, int NMT, int STAGE, int EPI, int KSPLIT, bool PLAIN>
 __global__ __launch_bounds__(256, 2) void plc_convr_kernel(const ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint4 plc_convr_smem[];
     plc_convr_body<NCB, NMT, STAGE, EPI, KSPLIT, PLAIN>(a, blockIdx.x, blockIdx.y, gridDim.y, plc_convr_smem);
+}
+
+// PW form of the two cells' data gradients (widths 16 -> 32 and 16 -> 16), alone and as the skewed pair.
+struct ConvrPwArgs {
+    ConvArgs c;
+    LstmBwdArgs pw;
+};
+template <int NCB, int NMT, int KSPLIT>
+__global__ __launch_bounds__(256, 2) void plc_convr_pw_kernel(const ConvrPwArgs p) {
+    extern __shared__ __attribute__((aligned(16))) uint4 plc_convr_smem[];
+    plc_convr_body<NCB, NMT, STAGE_CB8, EPI_ACT_CB8, KSPLIT, true, true>(p.c, blockIdx.x, 0, 1, plc_convr_smem, &p.pw);
+}
+struct ConvrPwPairArgs {
+    ConvrPwArgs c2, c1;
+    int n2;              // workgroups [0, n2) run c2
+};
+__global__ __launch_bounds__(256, 2) void plc_convr_pw_pair_kernel(const ConvrPwPairArgs p) {
+    extern __shared__ __attribute__((aligned(16))) uint4 plc_convr_smem[];
+    if ((int)blockIdx.x < p.n2)
+        plc_convr_body<16, 2, STAGE_CB8, EPI_ACT_CB8, 2, true, true>(p.c2.c, blockIdx.x, 0, 1, plc_convr_smem, &p.c2.pw);
+    else
+        plc_convr_body<8, 1, STAGE_CB8, EPI_ACT_CB8, 1, true, true>(p.c1.c, blockIdx.x - p.n2, 0, 1, plc_convr_smem, &p.c1.pw);
 }
 
 // The two data-gradient convs of one backward step of the two-cell recurrence that do not depend on each

@@ -175,3 +175,45 @@ def test_cell_data_gradient_segment_walk(gpu, B, cin, ch, H, W):
     for name, got, ref in (("dx", xg.grad, leaf[0].grad), ("dh", hg.grad, leaf[1].grad), ("dc", cg.grad, leaf[2].grad)):
         assert relmax(got.cpu(), ref) <= TOL, (name, relmax(got.cpu(), ref))
         assert rel_l2(got.cpu(), ref) <= TOL_L2, (name, rel_l2(got.cpu(), ref))
+
+
+def _digest_run(env_extra):
+    """Digest lines of devtools/grad_digest.py's two smallest cases in a fresh process (the library reads
+    its kernel-selection switches once per process)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import hashlib, sys, torch\n"
+        f"sys.path.insert(0, {root!r})\n"
+        "from pl_convlstm_gan_amd import Generator\n"
+        "gpu = torch.device('cuda:0')\n"
+        "for (B, T, H, W, seed) in [(2, 4, 37, 45, 8), (3, 3, 16, 70, 11), (1, 3, 64, 64, 5)]:\n"
+        "    torch.manual_seed(seed)\n"
+        "    m = Generator(hidden_dims=[16, 32], lu_channels=5, scale_factor=1).to(gpu)\n"
+        "    g = torch.Generator().manual_seed(seed + 1)\n"
+        "    rain = 10 * torch.rand(B, T, 1, H, W, generator=g) * (torch.rand(B, T, 1, H, W, generator=g) > 0.7)\n"
+        "    dem, lu = torch.rand(B, 1, H, W, generator=g), torch.rand(B, 5, H, W, generator=g)\n"
+        "    out = m(rain.to(gpu), dem.to(gpu), lu.to(gpu))\n"
+        "    (out * (torch.rand(out.shape, generator=g) + 0.5).to(gpu)).sum().backward()\n"
+        "    h = hashlib.sha256(out.detach().cpu().numpy().tobytes())\n"
+        "    for k, p in sorted(m.named_parameters()):\n"
+        "        h.update(p.grad.cpu().numpy().tobytes())\n"
+        "    print(h.hexdigest())\n")
+    env = dict(os.environ)
+    env.update(env_extra)
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=150)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return r.stdout.split()
+
+
+def test_kernel_selection_switches_do_not_change_a_bit(gpu):
+    """The alternative schedules of the backward recurrence promise bit-identical results: the default
+    (rolling-window data gradients, skewed paired launches), the tile-at-a-time convs, the unpaired loop and
+    the data-gradient convs that run the pointwise backward themselves (PLC_FUSED_PW=1) must give the
+    same digest of the output and of every parameter gradient, at ragged shapes included."""
+    base = _digest_run({})
+    assert len(base) == 3
+    for env in ({"PLC_NO_ROLLING": "1"}, {"PLC_NO_PAIRING": "1"}, {"PLC_FUSED_PW": "1"}):
+        assert _digest_run(env) == base, env
