@@ -294,7 +294,7 @@ static bool plc_no_rolling() {
 // resident (a single round) when the image is large enough for that.
 // Segment geometry of a rolling-window launch into `a`; returns its grid size, or an error code (negative).
 template <int NCB, int NMT, int STAGE, int EPI, int KSPLIT, bool PLAIN>
-static int convr_geometry(ConvArgs& a, int n_img, int n_mgroups) {
+static int convr_geometry(ConvArgs& a, int n_img, int n_mgroups, int slots_div = 1) {
     using R = PlcRoll<NCB, NMT, KSPLIT>;
     constexpr int lds = plc_convr_lds_bytes<NCB, NMT, KSPLIT, STAGE>();
     if (PLAIN && (EPI != EPI_ACT_CB8 || a.out1.p || a.mul.p || a.act == ACT_SIGMOID))
@@ -302,7 +302,8 @@ static int convr_geometry(ConvArgs& a, int n_img, int n_mgroups) {
     // (the kernel addresses a lane's unit of an input row with a 32-bit offset from the row's base)
     if ((long long)NCB * a.H * a.W * 16 >= (1ll << 32)) return plc_fail(PLC_EINVAL, "conv: image too large for the rolling-window kernel");
     constexpr int by_lds = (160 * 1024) / lds;
-    const int resident = cu_count() * (by_lds < 2 ? by_lds : 2) / n_mgroups;
+    // (slots_div: the launch is meant to share the chip with another one and aims at that fraction of the slots)
+    const int resident = cu_count() * (by_lds < 2 ? by_lds : 2) / n_mgroups / slots_div;
     a.tiles_x = cdiv(a.W, 32);
     const long long strips = (long long)n_img * a.tiles_x;
     const long long want = strips < resident ? resident / strips : 1;     // segments per strip

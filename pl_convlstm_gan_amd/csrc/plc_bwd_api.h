@@ -272,7 +272,7 @@ static int cell_dgrad(const void* dz, const void* wpkT, const float* bpk0, void*
 static int cell_dgrad_ksplit(int Cin, int Ch) { return (Cin == 16 && Ch == 32) ? 2 : 1; }
 
 // The data gradients of cell 2 (16 -> 32 hidden channels, step t - 1) and cell 1 (16 -> 16, step t) in one launch.
-static int cell_dgrad_pair(const ConvArgs& c2, const ConvArgs& c1, int B, hipStream_t st) {
+static int cell_dgrad_pair(const ConvArgs& c2, const ConvArgs& c1, int B, hipStream_t st, int slots_div = 1) {
     constexpr int lds2 = plc_convr_lds_bytes<16, 2, 2, STAGE_CB8>(), lds1 = plc_convr_lds_bytes<8, 1, 1, STAGE_CB8>();
     constexpr int lds = lds2 > lds1 ? lds2 : lds1;
     static bool lds_raised[64] = {false};
@@ -281,9 +281,9 @@ static int cell_dgrad_pair(const ConvArgs& c2, const ConvArgs& c1, int B, hipStr
     ConvrPairArgs p;
     p.c2 = c2;
     p.c1 = c1;
-    const int n2 = convr_geometry<16, 2, STAGE_CB8, EPI_ACT_CB8, 2, true>(p.c2, B, 1);
+    const int n2 = convr_geometry<16, 2, STAGE_CB8, EPI_ACT_CB8, 2, true>(p.c2, B, 1, slots_div);
     if (n2 < 0) return n2;
-    const int n1 = convr_geometry<8, 1, STAGE_CB8, EPI_ACT_CB8, 1, true>(p.c1, B, 1);
+    const int n1 = convr_geometry<8, 1, STAGE_CB8, EPI_ACT_CB8, 1, true>(p.c1, B, 1, slots_div);
     if (n1 < 0) return n1;
     p.n2 = n2;
     hipLaunchKernelGGL(plc_convr_dgrad_pair_kernel, dim3(n2 + n1), dim3(256), lds, st, p);
@@ -795,7 +795,77 @@ extern "C" int plc_generator_rollout_bwd(const plc_rollout_desc* d, const plc_ro
                                B, C1, C1, H, W);
     };
     const bool skew = fast && T > 1 && !plc_no_rolling() && !plc_no_pairing();
-    if (skew && plc_fused_pw()) {
+    static const bool no_split = [] { const char* e = getenv("PLC_NO_BWD_SPLIT"); return e && *e && *e != '0'; }();
+    if (skew && !no_split && !plc_fused_pw() && B >= 2) {
+        // The batch elements are independent, and the recurrence alternates an HBM-bound launch (pointwise
+        // passes) with an MFMA-bound one (data-gradient convs).  The two halves of the batch therefore run as
+        // two chains on two streams, the second one launch behind the first: one half's pointwise passes
+        // stream beside the other half's convs, which aim at one workgroup per CU (236 VGPRs: 276 of a SIMD's
+        // 512 stay free, room for three pointwise waves).  Same kernels, same per-image arithmetic, identical
+        // results; c3 / c2 / c4 train step -2.0 / -3.0 / -3.2 % on the same box.  The second stream and the
+        // three events of the fork and join are created once per device, on the first call, and kept.
+        static hipStream_t aux_s[64] = {nullptr};
+        static hipEvent_t ev_s[64][3] = {{nullptr}};
+        const int dev = current_device();
+        if (dev < 0) return plc_fail(PLC_EHIP, "no current device");
+        if (!aux_s[dev]) {
+            PLC_HIP(hipStreamCreateWithFlags(&aux_s[dev], hipStreamNonBlocking));
+            for (int k = 0; k < 3; ++k) PLC_HIP(hipEventCreateWithFlags(&ev_s[dev][k], hipEventDisableTiming));
+        }
+        hipStream_t sa = st, sb = aux_s[dev];
+        auto shift_pw = [&](LstmBwdArgs a, int b0, int nb) {
+            const long long uimg = (long long)a.ncb * a.H * a.W;      // units per image of an [B][ncb] tensor
+            Cb8View* vs[4] = {&a.dh0, &a.dh1, &a.dh2, &a.dh0_mul};
+            for (Cb8View* v : vs) if (v->p) v->p += (long long)b0 * v->img;
+            const int dcb = a.dc_bf16 ? 16 : 32;
+            if (a.dc_in) a.dc_in += b0 * uimg * dcb;
+            a.dc_out += b0 * uimg * dcb;
+            a.gates += b0 * 4 * uimg * 16;
+            if (a.c_prev) a.c_prev += b0 * uimg * 32;
+            a.dz += b0 * 4 * uimg * 16;
+            a.B = nb;
+            return a;
+        };
+        auto shift_cv = [&](ConvArgs a, int b0, int nb) {
+            a.src0.p = (char*)a.src0.p + (long long)b0 * a.src0.si;
+            a.out0.p = (char*)a.out0.p + (long long)b0 * a.out0.si;
+            a.n_in = nb;
+            return a;
+        };
+        const int nbh[2] = {B / 2, B - B / 2}, b0h[2] = {0, B / 2};
+        hipStream_t sh[2] = {sa, sb};
+        PLC_HIP(hipEventRecord(ev_s[dev][0], sa));
+        PLC_HIP(hipStreamWaitEvent(sb, ev_s[dev][0], 0));
+        // stage k of a chain: 0 = pw2(T-1), 1 = dg2(T-1), then for t = T-1..1: pair pw, pair dg; then pw1(0), dg1(0)
+        const int n_stage = 2 + 2 * (T - 1) + 2;
+        auto run_stage = [&](int h, int k) -> int {
+            const int b0 = b0h[h], nb = nbh[h];
+            hipStream_t s = sh[h];
+            if (k == 0) return lstm_pointwise_bwd_launch(shift_pw(pw2_args(T - 1), b0, nb), s);
+            if (k == 1) {
+                const ConvArgs c = shift_cv(dg2_args(T - 1), b0, nb);
+                return launch_convr<16, 2, STAGE_CB8, EPI_ACT_CB8, 2, true>(c, nb, 1, s);
+            }
+            if (k >= n_stage - 2) {
+                if (k == n_stage - 2) return lstm_pointwise_bwd_launch(shift_pw(pw1_args(0), b0, nb), s);
+                const ConvArgs c = shift_cv(dg1_args(0), b0, nb);
+                return launch_convr<8, 1, STAGE_CB8, EPI_ACT_CB8, 1, true>(c, nb, 1, s);
+            }
+            const int t = T - 1 - (k - 2) / 2;
+            if ((k & 1) == 0) return lstm_pointwise_bwd_launch_pair(shift_pw(pw2_args(t - 1), b0, nb), shift_pw(pw1_args(t), b0, nb), s);
+            return cell_dgrad_pair(shift_cv(dg2_args(t - 1), b0, nb), shift_cv(dg1_args(t), b0, nb), nb, s, 2);
+        };
+        // chain B starts one stage behind chain A
+        if ((rc = run_stage(0, 0))) return rc;
+        PLC_HIP(hipEventRecord(ev_s[dev][1], sa));
+        PLC_HIP(hipStreamWaitEvent(sb, ev_s[dev][1], 0));
+        for (int k = 1; k <= n_stage; ++k) {
+            if (k < n_stage && (rc = run_stage(0, k))) return rc;
+            if ((rc = run_stage(1, k - 1))) return rc;
+        }
+        PLC_HIP(hipEventRecord(ev_s[dev][2], sb));
+        PLC_HIP(hipStreamWaitEvent(sa, ev_s[dev][2], 0));
+    } else if (skew && plc_fused_pw()) {
         // T + 1 launches: each conv forms its own input (the pointwise pass runs inside it)
         if ((rc = cell_dgrad_pw<16, 2, 2>(pw2_args(T - 1), dg2_args(T - 1), B, st))) return rc;
         for (int t = T - 1; t >= 1; --t)

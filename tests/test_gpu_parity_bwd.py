@@ -210,10 +210,11 @@ def _digest_run(env_extra):
 
 def test_kernel_selection_switches_do_not_change_a_bit(gpu):
     """The alternative schedules of the backward recurrence promise bit-identical results: the default
-    (rolling-window data gradients, skewed paired launches), the tile-at-a-time convs, the unpaired loop and
+    (rolling-window data gradients, skewed paired launches, the batch's halves on two streams), the
+    tile-at-a-time convs, the unpaired loop, the single chain and
     the data-gradient convs that run the pointwise backward themselves (PLC_FUSED_PW=1) must give the
     same digest of the output and of every parameter gradient, at ragged shapes included."""
     base = _digest_run({})
     assert len(base) == 3
-    for env in ({"PLC_NO_ROLLING": "1"}, {"PLC_NO_PAIRING": "1"}, {"PLC_FUSED_PW": "1"}):
+    for env in ({"PLC_NO_ROLLING": "1"}, {"PLC_NO_PAIRING": "1"}, {"PLC_FUSED_PW": "1"}, {"PLC_NO_BWD_SPLIT": "1"}):
         assert _digest_run(env) == base, env
