@@ -249,6 +249,29 @@ static int ensure_lds_limit(const void* kern, int lds, bool (&done)[64]) {
     return PLC_OK;
 }
 
+// A second stream per device and the three events of a fork / join around it, created on first use and
+// kept for the life of the process: the rollouts run the two halves of a batch as two chains of launches,
+// one on the caller's stream and one here (batch elements are independent), so that one half's
+// memory-bound phases run beside the other half's arithmetic.  Fork and join are event record / wait
+// pairs, which a stream capture follows.
+struct PlcAux {
+    hipStream_t stream;
+    hipEvent_t ev[3];
+};
+static int plc_aux(PlcAux** out) {
+    static PlcAux aux[64];
+    static bool made[64] = {false};
+    const int dev = current_device();
+    if (dev < 0) return plc_fail(PLC_EHIP, "no current device");
+    if (!made[dev]) {
+        PLC_HIP(hipStreamCreateWithFlags(&aux[dev].stream, hipStreamNonBlocking));
+        for (int k = 0; k < 3; ++k) PLC_HIP(hipEventCreateWithFlags(&aux[dev].ev[k], hipEventDisableTiming));
+        made[dev] = true;
+    }
+    *out = &aux[dev];
+    return PLC_OK;
+}
+
 // One instantiation at a fixed tile height TH (and K split).
 template <int NCB0, int NCB1, int NMT, int KS, int STAGE, int EPI, int TH, int KSPLIT = 1>
 static int launch_conv_th(ConvArgs a, int n_img, int n_mgroups, hipStream_t st) {
@@ -269,6 +292,45 @@ static int launch_conv_th(ConvArgs a, int n_img, int n_mgroups, hipStream_t st) 
     const int per_wg = plc_conv_multi_tile<STAGE, EPI>() ? cdiv(a.n_tiles, resident > 0 ? resident : 1) : 1;
     a.n_blocks = cdiv(a.n_tiles, per_wg);
     hipLaunchKernelGGL(kern, dim3(a.n_blocks, n_mgroups), dim3(256), lds, st, a);
+    PLC_HIP(hipGetLastError());
+    return PLC_OK;
+}
+
+// The gated conv over T time steps of B images each (images n = t * B + b, multiplier tensor indexed by b
+// alone): tiles are walked time-innermost, so the multiplier tile of a (b, position) is fetched once per
+// chain of time steps instead of once per tile.  A position's T steps are cut into the fewest chains that
+// still give every resident workgroup slot a chain (PLC_GATED_TSEGS overrides the count: measurements).
+// Results do not depend on the tile order.
+template <int NCB0, int NMT, int KS, int EPI, int TH>
+static int launch_conv_gated_tinner(ConvArgs a, int B, int T, hipStream_t st) {
+    constexpr int lds = plc_conv_lds_bytes<NCB0, KS, TH, 1, STAGE_CB8_GATED>();
+    auto kern = plc_conv_mfma_kernel<NCB0, 0, NMT, KS, STAGE_CB8_GATED, EPI, TH, 1>;
+    if (lds > 65536) {
+        static bool lds_raised[64] = {false};
+        int rc = ensure_lds_limit((const void*)kern, lds, lds_raised);
+        if (rc) return rc;
+    }
+    a.n_in = B;
+    a.tiles_x = cdiv(a.W, 32);
+    a.tiles_y = cdiv(a.H, TH);
+    const long long positions = (long long)B * a.tiles_x * a.tiles_y;
+    if (positions * T >= (1ll << 31)) return plc_fail(PLC_EINVAL, "conv: bad tile count");
+    a.n_tiles = (int)(positions * T);
+    constexpr int by_waves = plc_conv_min_waves<NCB0, KS, 1, NMT, EPI>();
+    constexpr int by_lds = (160 * 1024) / lds;
+    const int resident = cu_count() * (by_waves < by_lds ? by_waves : by_lds);
+    static const int forced = [] { const char* e = getenv("PLC_GATED_TSEGS"); return e ? atoi(e) : 0; }();
+    int segs = T;
+    for (int k = 1; k <= T; ++k)
+        if (T % k == 0 && (positions * k >= 2ll * resident || k == T)) { segs = k; break; }
+    if (forced > 0 && T % forced == 0) segs = forced;
+    a.t_segs = segs;
+    a.t_inner = T / segs;
+    const long long chains = positions * segs;
+    const long long slots = resident > 0 ? resident : 1;
+    const long long per_wg = (chains + slots - 1) / slots;
+    a.n_blocks = (int)((chains + per_wg - 1) / per_wg);
+    hipLaunchKernelGGL(kern, dim3(a.n_blocks, 1), dim3(256), lds, st, a);
     PLC_HIP(hipGetLastError());
     return PLC_OK;
 }
@@ -528,13 +590,14 @@ static int launch_pair_th(PairArgs p, int n_img, hipStream_t st) {
 }
 
 // widths [16,32] only; the tile height follows launch_conv's rule so that results equal the single launches'
-static int launch_pair(const ConvArgs& c2, const ConvArgs& c1, int n_img, hipStream_t st) {
+// (n_rule: the image count the tile-height rule is applied to -- a half-batch chain keeps the whole batch's tiles)
+static int launch_pair(const ConvArgs& c2, const ConvArgs& c1, int n_img, hipStream_t st, int n_rule = 0) {
     PairArgs p;
     memset(&p, 0, sizeof(p));
     p.c2 = c2;
     p.c1 = c1;
     const bool save = c2.save_gates != 0;
-    const long long t16 = (long long)n_img * cdiv(c2.H, 16) * cdiv(c2.W, 32);
+    const long long t16 = (long long)(n_rule > 0 ? n_rule : n_img) * cdiv(c2.H, 16) * cdiv(c2.W, 32);
     if (t16 >= 512) return save ? launch_pair_th<16, true>(p, n_img, st) : launch_pair_th<16, false>(p, n_img, st);
     return save ? launch_pair_th<8, true>(p, n_img, st) : launch_pair_th<8, false>(p, n_img, st);
 }
@@ -1050,7 +1113,50 @@ extern "C" int plc_generator_rollout_fwd(const plc_rollout_desc* d, void* stream
             pa.c1.sync = pa.c2.sync = (unsigned*)(ws + p.sync);
             if ((rc = launch_persistent(pa, B, T, save, st, &persistent))) return rc;
         }
-        if (!persistent && fast && T > 1 && !plc_no_pairing()) {
+        static const bool no_fwd_split = [] { const char* e = getenv("PLC_NO_FWD_SPLIT"); return e && *e && *e != '0'; }();
+        const long long t16_all = (long long)B * cdiv(H, 16) * cdiv(W, 32);
+        if (!persistent && fast && T > 1 && !plc_no_pairing() && !no_fwd_split && B >= 2 && t16_all >= 512) {
+            // Two half-batch chains on two streams, the second one launch behind the first (as the backward
+            // recurrence does): a cell launch starts with a burst of weight and halo-tile fetches and ends with
+            // a drain, during which the other chain's workgroups have the matrix pipes.  Same kernels, same
+            // tiles per image, identical results.
+            PlcAux* aux = nullptr;
+            if ((rc = plc_aux(&aux))) return rc;
+            hipStream_t sh[2] = {st, aux->stream};
+            const int nbh[2] = {B / 2, B - B / 2}, b0h[2] = {0, B / 2};
+            auto half = [&](ConvArgs a, int h) {
+                PlcTensor* ts[6] = {&a.src0, &a.src1, &a.c_in, &a.out0, &a.out1, &a.out2};
+                for (PlcTensor* t : ts) if (t->p) t->p += (long long)b0h[h] * t->si;
+                a.n_in = nbh[h];
+                return a;
+            };
+            // stage k of a chain: 0 = cell 1 (0); k = 1 .. T-1: cell 2 (k-1) + cell 1 (k); T = cell 2 (T-1)
+            auto stage = [&](int h, int k) -> int {
+                const int nb = nbh[h];
+                if (k == 0) {
+                    ConvArgs a = half(cell1(0), h);
+                    return save ? launch_conv_th<2, 2, 2, 3, STAGE_CB8, EPI_LSTM_SAVE, 16>(a, nb, 1, sh[h])
+                                : launch_conv_th<2, 2, 2, 3, STAGE_CB8, EPI_LSTM, 16>(a, nb, 1, sh[h]);
+                }
+                if (k == T) {
+                    ConvArgs a = half(cell2(T - 1), h);
+                    return save ? launch_conv_th<2, 4, 4, 3, STAGE_CB8, EPI_LSTM_SAVE, 16>(a, nb, 1, sh[h])
+                                : launch_conv_th<2, 4, 4, 3, STAGE_CB8, EPI_LSTM, 16>(a, nb, 1, sh[h]);
+                }
+                return launch_pair(half(cell2(k - 1), h), half(cell1(k), h), nb, sh[h], B);
+            };
+            PLC_HIP(hipEventRecord(aux->ev[0], st));
+            PLC_HIP(hipStreamWaitEvent(aux->stream, aux->ev[0], 0));
+            if ((rc = stage(0, 0))) return rc;
+            PLC_HIP(hipEventRecord(aux->ev[1], st));
+            PLC_HIP(hipStreamWaitEvent(aux->stream, aux->ev[1], 0));
+            for (int k = 1; k <= T + 1; ++k) {
+                if (k <= T && (rc = stage(0, k))) return rc;
+                if ((rc = stage(1, k - 1))) return rc;
+            }
+            PLC_HIP(hipEventRecord(aux->ev[2], aux->stream));
+            PLC_HIP(hipStreamWaitEvent(st, aux->ev[2], 0));
+        } else if (!persistent && fast && T > 1 && !plc_no_pairing()) {
             // cell 1 (0) | cell 2 (t-1) + cell 1 (t), t = 1 .. T-1 | cell 2 (T-1)
             if ((rc = launch_cell(cell1(0), B, C1, C1, st))) return rc;
             for (int t = 1; t < T; ++t)
@@ -1107,8 +1213,10 @@ extern "C" int plc_generator_rollout_fwd(const plc_rollout_desc* d, void* stream
         a.bpk = (const float*)(ws + p.post0.b);
         a.act = ACT_RELU;
         a.ncb_out = 4;
-        if ((rc = fast ? launch_conv<4, 0, 1, 3, STAGE_CB8_GATED, EPI_ACT_CB8>(a, NI, 1, st)
-                       : launch_convg<3, STAGE_CB8_GATED, EPI_ACT_CB8>(a, C2 / 8, 0, 1, NI, st)))
+        static const bool no_tinner = [] { const char* e = getenv("PLC_NO_GATED_TINNER"); return e && *e && *e != '0'; }();
+        if ((rc = !fast ? launch_convg<3, STAGE_CB8_GATED, EPI_ACT_CB8>(a, C2 / 8, 0, 1, NI, st)
+                  : (T > 1 && !no_tinner) ? launch_conv_gated_tinner<4, 1, 3, EPI_ACT_CB8, 8>(a, B, T, st)
+                                          : launch_conv<4, 0, 1, 3, STAGE_CB8_GATED, EPI_ACT_CB8>(a, NI, 1, st)))
             return rc;
 
         a = conv_args(oH, oW, B);

@@ -802,17 +802,11 @@ extern "C" int plc_generator_rollout_bwd(const plc_rollout_desc* d, const plc_ro
         // two chains on two streams, the second one launch behind the first: one half's pointwise passes
         // stream beside the other half's convs, which aim at one workgroup per CU (236 VGPRs: 276 of a SIMD's
         // 512 stay free, room for three pointwise waves).  Same kernels, same per-image arithmetic, identical
-        // results; c3 / c2 / c4 train step -2.0 / -3.0 / -3.2 % on the same box.  The second stream and the
-        // three events of the fork and join are created once per device, on the first call, and kept.
-        static hipStream_t aux_s[64] = {nullptr};
-        static hipEvent_t ev_s[64][3] = {{nullptr}};
-        const int dev = current_device();
-        if (dev < 0) return plc_fail(PLC_EHIP, "no current device");
-        if (!aux_s[dev]) {
-            PLC_HIP(hipStreamCreateWithFlags(&aux_s[dev], hipStreamNonBlocking));
-            for (int k = 0; k < 3; ++k) PLC_HIP(hipEventCreateWithFlags(&ev_s[dev][k], hipEventDisableTiming));
-        }
-        hipStream_t sa = st, sb = aux_s[dev];
+        // results; c3 / c2 / c4 train step -2.0 / -3.0 / -3.2 % on the same box.
+        PlcAux* aux = nullptr;
+        if ((rc = plc_aux(&aux))) return rc;
+        hipEvent_t* const ev = aux->ev;
+        hipStream_t sa = st, sb = aux->stream;
         auto shift_pw = [&](LstmBwdArgs a, int b0, int nb) {
             const long long uimg = (long long)a.ncb * a.H * a.W;      // units per image of an [B][ncb] tensor
             Cb8View* vs[4] = {&a.dh0, &a.dh1, &a.dh2, &a.dh0_mul};
@@ -834,8 +828,8 @@ extern "C" int plc_generator_rollout_bwd(const plc_rollout_desc* d, const plc_ro
         };
         const int nbh[2] = {B / 2, B - B / 2}, b0h[2] = {0, B / 2};
         hipStream_t sh[2] = {sa, sb};
-        PLC_HIP(hipEventRecord(ev_s[dev][0], sa));
-        PLC_HIP(hipStreamWaitEvent(sb, ev_s[dev][0], 0));
+        PLC_HIP(hipEventRecord(ev[0], sa));
+        PLC_HIP(hipStreamWaitEvent(sb, ev[0], 0));
         // stage k of a chain: 0 = pw2(T-1), 1 = dg2(T-1), then for t = T-1..1: pair pw, pair dg; then pw1(0), dg1(0)
         const int n_stage = 2 + 2 * (T - 1) + 2;
         auto run_stage = [&](int h, int k) -> int {
@@ -857,14 +851,14 @@ extern "C" int plc_generator_rollout_bwd(const plc_rollout_desc* d, const plc_ro
         };
         // chain B starts one stage behind chain A
         if ((rc = run_stage(0, 0))) return rc;
-        PLC_HIP(hipEventRecord(ev_s[dev][1], sa));
-        PLC_HIP(hipStreamWaitEvent(sb, ev_s[dev][1], 0));
+        PLC_HIP(hipEventRecord(ev[1], sa));
+        PLC_HIP(hipStreamWaitEvent(sb, ev[1], 0));
         for (int k = 1; k <= n_stage; ++k) {
             if (k < n_stage && (rc = run_stage(0, k))) return rc;
             if ((rc = run_stage(1, k - 1))) return rc;
         }
-        PLC_HIP(hipEventRecord(ev_s[dev][2], sb));
-        PLC_HIP(hipStreamWaitEvent(sa, ev_s[dev][2], 0));
+        PLC_HIP(hipEventRecord(ev[2], sb));
+        PLC_HIP(hipStreamWaitEvent(sa, ev[2], 0));
     } else if (skew && plc_fused_pw()) {
         // T + 1 launches: each conv forms its own input (the pointwise pass runs inside it)
         if ((rc = cell_dgrad_pw<16, 2, 2>(pw2_args(T - 1), dg2_args(T - 1), B, st))) return rc;

@@ -72,6 +72,7 @@ struct ConvArgs {
     int g_ncb0, g_ncb1;  // run-time-width kernel (plc_convg_kernel.h) only: channel blocks of src0 / src1
     int g_nmt;           // ... and the conv's 32-row output tiles
     int seg_rows;        // rolling-window kernel (plc_convr_kernel.h) only: rows per segment
+    int t_inner, t_segs; // gated staging only, t_inner > 0: tiles are walked time-innermost (see plc_decode_tile)
     unsigned* sync;      // persistent recurrence (PERSIST != 0): the device-wide barrier's counter, zero at launch
     PlcTensor src0;      // CB8 bf16, first NCB0 channel blocks   (STAGE_COORD / STAGE_F32_1CH: fp32 plane)
     PlcTensor src1;      // CB8 bf16, next NCB1 channel blocks
@@ -431,9 +432,10 @@ constexpr bool plc_conv_multi_tile() {
 // GATE_OFF units after the tile.  SPLIT: the pieces holding rows that pass 0 of each of the RG row
 // groups reads are requested first; the return value is the number of later pieces this wave issued
 // (loads retire in order, so "all but the n_late youngest" is exactly the early set).
+// with_gate (wave-uniform) = false: the multiplier's tile is already in LDS (same pixels, an earlier time step).
 template <int NCB0, int NCB1, int KS, int TH, int STAGE, bool SPLIT, int RG, int RPW, int NREP, int TILE_UNITS, int GATE_OFF>
 __device__ __forceinline__ int plc_dma_issue(const ConvArgs& a, uint4* tile, int lane, int wave_u, int n, int x0, int y0,
-                                             int zero_state) {
+                                             int zero_state, bool with_gate = true) {
     constexpr int NCB = NCB0 + NCB1, PAD = KS / 2, LH = TH + 2 * PAD, LW = 32 + 2 * PAD, PLANE = LH * LW;
     constexpr int NCHUNK = TILE_UNITS / 64;
     const int H = a.H, W = a.W;
@@ -467,22 +469,52 @@ __device__ __forceinline__ int plc_dma_issue(const ConvArgs& a, uint4* tile, int
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)(tile + ch * 64), 16, 0, 0);
             if constexpr (STAGE == STAGE_CB8_GATED) {
-                const char* gsrc = ok ? gt + poff : (const char*)&plc_zero16;
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
-                                                 (__attribute__((address_space(3))) void*)(tile + GATE_OFF + ch * 64), 16, 0, 0);
+                if (with_gate) {
+                    const char* gsrc = ok ? gt + poff : (const char*)&plc_zero16;
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                                     (__attribute__((address_space(3))) void*)(tile + GATE_OFF + ch * 64), 16, 0, 0);
+                }
             }
         }
     return n_late;
 }
 
 // Tile index (image-major, then tile row, then tile column) -> image and pixel origin.
+// Time-innermost order (a.t_inner > 0; the images are n = t * n_in + b): the index runs over the t_inner
+// time steps of a chain first, then over the t_segs chains of a (b, tile row, tile column) position, then
+// over the positions, so that a workgroup meets the same pixels of consecutive time steps one after
+// another and whatever depends on b and the position alone -- the multiplier tile of the gated
+// staging -- stays in LDS along a chain.
 __device__ __forceinline__ void plc_decode_tile(const ConvArgs& a, int th, int id, int& n, int& x0, int& y0) {
+    if (a.t_inner > 0) {
+        const int tt = id % a.t_inner;
+        id /= a.t_inner;
+        const int seg = id % a.t_segs;
+        id /= a.t_segs;
+        const int tx = id % a.tiles_x;
+        id /= a.tiles_x;
+        const int ty = id % a.tiles_y;
+        n = (seg * a.t_inner + tt) * a.n_in + id / a.tiles_y;
+        x0 = tx * 32;
+        y0 = ty * th;
+        return;
+    }
     const int tx = id % a.tiles_x;
     id /= a.tiles_x;
     const int ty = id % a.tiles_y;
     n = id / a.tiles_y;
     x0 = tx * 32;
     y0 = ty * th;
+}
+
+// A workgroup's first tile and the one after `id`: tiles block_x, block_x + n_blocks, ...; in the
+// time-innermost order CHAINS block_x, block_x + n_blocks, ..., each walked through its t_inner steps.
+__device__ __forceinline__ int plc_first_tile(const ConvArgs& a, int block_x) {
+    return a.t_inner > 0 ? block_x * a.t_inner : block_x;
+}
+__device__ __forceinline__ int plc_next_tile(const ConvArgs& a, int id) {
+    if (a.t_inner > 0) return (id + 1) % a.t_inner ? id + 1 : id + 1 + (a.n_blocks - 1) * a.t_inner;
+    return id + a.n_blocks;
 }
 
 // The work of one workgroup: tile `block_x` (image-major, then tile row, then tile column) of M
@@ -588,9 +620,9 @@ __device__ __forceinline__ void plc_conv_body(const ConvArgs& a, const int block
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     // (free functions and a macro rather than capturing lambdas: this compiler's simplifycfg crashes
     // on lambdas of this shape in the multi-tile instantiations)
-#define PLC_DMA_ISSUE(n_, x0_, y0_)                                                                     \
+#define PLC_DMA_ISSUE(n_, x0_, y0_, gate_)                                                              \
     plc_dma_issue<NCB0, NCB1, KS, TH, STAGE, SPLIT_STAGE, RG, RPW, NREP, TILE_UNITS,                    \
-                  TILE_UNITS + RED_UNITS + BIAS_UNITS>(a, tile, lane, wave_u, n_, x0_, y0_, zs)
+                  TILE_UNITS + RED_UNITS + BIAS_UNITS>(a, tile, lane, wave_u, n_, x0_, y0_, zs, gate_)
     // Multi-tile workgroups request tile k+1 as soon as every wave has finished READING tile k (after
     // the last pass's MFMA loop), so the transfer runs under that pass's stores: the epilogue does
     // not touch the LDS tile.  (Timeline of the gated post conv before: 3.4 us tile wait, 0.9 us
@@ -600,24 +632,25 @@ __device__ __forceinline__ void plc_conv_body(const ConvArgs& a, const int block
     int zs = a.zero_state;      // (PERSIST: cleared after the first step)
     if constexpr (PREFETCH) {
         int n_, x0_, y0_;
-        plc_decode_tile(a, TH, block_x, n_, x0_, y0_);
-        PLC_DMA_ISSUE(n_, x0_, y0_);
+        plc_decode_tile(a, TH, plc_first_tile(a, block_x), n_, x0_, y0_);
+        PLC_DMA_ISSUE(n_, x0_, y0_, true);
     }
     // every wave runs this once per tile (it contains a workgroup barrier)
 #define PLC_PREFETCH_NEXT()                                                                             \
     do {                                                                                                \
         if constexpr (PREFETCH) {                                                                       \
-            const int next_ = tile_id + a.n_blocks;                                                     \
+            const int next_ = plc_next_tile(a, tile_id);                                                \
             if (next_ < a.n_tiles) {                                                                    \
                 plc_lds_barrier(); /* every wave is done reading the current tile */                    \
                 int pn_, px0_, py0_;                                                                    \
                 plc_decode_tile(a, TH, next_, pn_, px0_, py0_);                                         \
-                PLC_DMA_ISSUE(pn_, px0_, py0_);                                                         \
+                /* (time-innermost order: the multiplier tile is fetched at the head of a chain only) */ \
+                PLC_DMA_ISSUE(pn_, px0_, py0_, a.t_inner == 0 || next_ % a.t_inner == 0);               \
             }                                                                                           \
         }                                                                                               \
     } while (0)
 #pragma unroll 1
-    for (int tile_id = block_x; tile_id < a.n_tiles; tile_id += a.n_blocks) {
+    for (int tile_id = plc_first_tile(a, block_x); tile_id < a.n_tiles; tile_id = plc_next_tile(a, tile_id)) {
     if constexpr (PERSIST != 0) {
         const int step = (tile_id - block_x) / a.n_blocks;
         zs = step == 0 ? a.zero_state : 0;
@@ -637,7 +670,7 @@ __device__ __forceinline__ void plc_conv_body(const ConvArgs& a, const int block
             // previous tile's last pass).  Gated staging: the product (rounded to bf16 once)
             // replaces the tile in a pass over LDS.
             int n_late = 0;
-            if constexpr (!PREFETCH) n_late = PLC_DMA_ISSUE(n, x0, y0);
+            if constexpr (!PREFETCH) n_late = PLC_DMA_ISSUE(n, x0, y0, true);
             if constexpr (SPLIT_STAGE) plc_wait_vmcnt_le(n_late);
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if constexpr (STAGE == STAGE_CB8_GATED) {

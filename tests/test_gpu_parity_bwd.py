@@ -189,7 +189,7 @@ def _digest_run(env_extra):
         f"sys.path.insert(0, {root!r})\n"
         "from pl_convlstm_gan_amd import Generator\n"
         "gpu = torch.device('cuda:0')\n"
-        "for (B, T, H, W, seed) in [(2, 4, 37, 45, 8), (3, 3, 16, 70, 11), (1, 3, 64, 64, 5)]:\n"
+        "for (B, T, H, W, seed) in [(2, 4, 37, 45, 8), (3, 3, 16, 70, 11), (1, 3, 64, 64, 5), (4, 2, 256, 256, 3)]:\n"
         "    torch.manual_seed(seed)\n"
         "    m = Generator(hidden_dims=[16, 32], lu_channels=5, scale_factor=1).to(gpu)\n"
         "    g = torch.Generator().manual_seed(seed + 1)\n"
@@ -209,12 +209,15 @@ def _digest_run(env_extra):
 
 
 def test_kernel_selection_switches_do_not_change_a_bit(gpu):
-    """The alternative schedules of the backward recurrence promise bit-identical results: the default
-    (rolling-window data gradients, skewed paired launches, the batch's halves on two streams), the
-    tile-at-a-time convs, the unpaired loop, the single chain and
+    """The alternative schedules of the rollout promise bit-identical results: the default
+    (rolling-window data gradients, skewed paired launches, the batch's halves on two streams in both
+    recurrences, the gated post conv walking its tiles time-innermost), the
+    tile-at-a-time convs, the unpaired loop, the single chains, the image-major gated conv and
     the data-gradient convs that run the pointwise backward themselves (PLC_FUSED_PW=1) must give the
-    same digest of the output and of every parameter gradient, at ragged shapes included."""
+    same digest of the output and of every parameter gradient, at ragged shapes included (the last shape is
+    large enough for the forward recurrence to run as two chains)."""
     base = _digest_run({})
-    assert len(base) == 3
-    for env in ({"PLC_NO_ROLLING": "1"}, {"PLC_NO_PAIRING": "1"}, {"PLC_FUSED_PW": "1"}, {"PLC_NO_BWD_SPLIT": "1"}):
+    assert len(base) == 4
+    for env in ({"PLC_NO_ROLLING": "1"}, {"PLC_NO_PAIRING": "1"}, {"PLC_FUSED_PW": "1"}, {"PLC_NO_BWD_SPLIT": "1"},
+                {"PLC_NO_FWD_SPLIT": "1"}, {"PLC_NO_GATED_TINNER": "1"}):
         assert _digest_run(env) == base, env
