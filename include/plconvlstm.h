@@ -327,6 +327,27 @@ int plc_clip_adam_step_guarded(const plc_opt_tensor* t, int n, double max_norm, 
                                double eps, double weight_decay, const float* guard, long long* step_counter,
                                int* skipped, float* grad_norm, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---------------------------------------------------------------------------------------
+ * Data-parallel gradient exchange: the two ends of the ONE all-reduce of a training step.
+ * No counterpart in the reference (single process, single device: src/training/trainer.py:20); they stand
+ * where DistributedDataParallel's bucket copies would, between loss.backward() (trainer.py:310) and
+ * clip_grad_norm_ (trainer.py:311).  The caller owns `flat` and performs the collective itself
+ * (all-reduce SUM over the ranks) between the two calls.
+ *
+ *   plc_dp_pack_grads    flat[0 .. G) = n_local * (the gradients of the table, in table order),
+ *                        flat[G] = 1 if *guard is NaN else 0 (guard NULL: 0), flat[G + 1] = n_local;
+ *                        G = sum of numel, flat_elems must be G + 2.  One launch.
+ *   plc_dp_unpack_grads  after the SUM: every gradient of the table = flat[i] / flat[G + 1] (the per-sample
+ *                        mean over the global batch when n_local was each rank's sample count), and, when
+ *                        guard_out is not NULL, *guard_out = NaN if flat[G] > 0 or is NaN (some rank's loss
+ *                        was NaN: every rank then skips the step) else *guard_in.  One launch.
+ * Only `grad` and `numel` of the table entries are read.
+ * ------------------------------------------------------------------------------------- */
+int plc_dp_pack_grads(const plc_opt_tensor* t, int n, float* flat, long long flat_elems, float n_local,
+                      const float* guard, void* stream);
+int plc_dp_unpack_grads(const plc_opt_tensor* t, int n, const float* flat, long long flat_elems,
+                        const float* guard_in, float* guard_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

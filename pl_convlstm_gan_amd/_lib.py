@@ -24,6 +24,7 @@ EXPORTS = (
     "plc_generator_bwd_workspace_bytes", "plc_generator_rollout_bwd",
     "plc_combined_loss_workspace_bytes", "plc_combined_loss",
     "plc_clip_adam_workspace_bytes", "plc_clip_adam_step", "plc_clip_adam_step_guarded",
+    "plc_dp_pack_grads", "plc_dp_unpack_grads",
 )
 
 _f = C.c_void_p   # device pointers travel as plain addresses
@@ -156,6 +157,10 @@ def lib():
     L.plc_clip_adam_step_guarded.restype = i
     L.plc_clip_adam_step_guarded.argtypes = [C.POINTER(OptTensor), i, C.c_double, C.c_double, C.c_double, C.c_double,
                                              C.c_double, C.c_double, p, p, p, p, p, sz, p]
+    L.plc_dp_pack_grads.restype = i
+    L.plc_dp_pack_grads.argtypes = [C.POINTER(OptTensor), i, p, C.c_longlong, C.c_float, p, p]
+    L.plc_dp_unpack_grads.restype = i
+    L.plc_dp_unpack_grads.argtypes = [C.POINTER(OptTensor), i, p, C.c_longlong, p, p, p]
     _lib = L
     return L
 

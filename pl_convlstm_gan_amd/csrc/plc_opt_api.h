@@ -118,3 +118,55 @@ extern "C" int plc_clip_adam_step_guarded(const plc_opt_tensor* t, int n, double
     return clip_adam_impl("plc_clip_adam_step_guarded", t, n, max_norm, lr, beta1, beta2, eps, weight_decay, true, 0,
                           guard, step_counter, skipped, grad_norm, workspace, workspace_bytes, stream);
 }
+
+// ---------------------------------------------------------------------------------------------
+// data-parallel gradient exchange (see include/plconvlstm.h)
+// ---------------------------------------------------------------------------------------------
+static int dp_grads_impl(const char* who, bool pack, const plc_opt_tensor* t, int n, float* flat, long long flat_elems,
+                         float n_local, const float* guard_in, float* guard_out, void* stream) {
+    PLC_REQUIRE(t && n > 0 && flat, "%s: empty tensor table or null buffer", who);
+    long long total = 0;
+    for (int k = 0; k < n; ++k) {
+        PLC_REQUIRE(t[k].numel > 0 && t[k].grad, "%s: tensor %d has no gradient or no elements", who, k);
+        total += t[k].numel;
+    }
+    PLC_REQUIRE(flat_elems == total + 2, "%s: the flat buffer must hold the %lld gradient elements + 2, not %lld", who, total,
+                flat_elems);
+    PLC_REQUIRE(!pack || n_local > 0.0f, "%s: n_local must be positive", who);
+    hipStream_t st = (hipStream_t)stream;
+    float* tail = flat + total;
+    long long done = 0;
+    for (int first = 0; first < n; first += OPT_MAX_TENSORS) {
+        const int cnt = n - first < OPT_MAX_TENSORS ? n - first : OPT_MAX_TENSORS;
+        OptTable tb;
+        memset(&tb, 0, sizeof(tb));
+        tb.n = cnt;
+        long long off = 0;
+        for (int k = 0; k < cnt; ++k) {
+            tb.grad[k] = t[first + k].grad;
+            tb.start[k] = off;
+            off += t[first + k].numel;
+        }
+        tb.start[cnt] = off;
+        const bool head = first == 0;       // the first launch also handles the two trailing elements
+        if (pack)
+            hipLaunchKernelGGL(plc_dp_pack_kernel, dim3(opt_blocks(off)), dim3(256), 0, st, tb, flat + done, n_local, guard_in,
+                               head ? tail : (float*)nullptr);
+        else
+            hipLaunchKernelGGL(plc_dp_unpack_kernel, dim3(opt_blocks(off)), dim3(256), 0, st, tb, (const float*)(flat + done),
+                               (const float*)tail, guard_in, head ? guard_out : (float*)nullptr);
+        PLC_HIP(hipGetLastError());
+        done += off;
+    }
+    return PLC_OK;
+}
+
+extern "C" int plc_dp_pack_grads(const plc_opt_tensor* t, int n, float* flat, long long flat_elems, float n_local,
+                                 const float* guard, void* stream) {
+    return dp_grads_impl("plc_dp_pack_grads", true, t, n, flat, flat_elems, n_local, guard, nullptr, stream);
+}
+
+extern "C" int plc_dp_unpack_grads(const plc_opt_tensor* t, int n, const float* flat, long long flat_elems,
+                                   const float* guard_in, float* guard_out, void* stream) {
+    return dp_grads_impl("plc_dp_unpack_grads", false, t, n, (float*)flat, flat_elems, 1.0f, guard_in, guard_out, stream);
+}

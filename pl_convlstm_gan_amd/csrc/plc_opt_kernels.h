@@ -134,3 +134,47 @@ __global__ __launch_bounds__(256) void plc_clip_adam_kernel(const OptTable tb, c
         tb.param[k][i] = p;
     }
 }
+
+// ---------------------------------------------------------------------------------------------
+// Data-parallel gradient exchange: gather the table's gradients into one flat buffer (scaled by this
+// rank's sample count, with the NaN flag and the count as two trailing elements) and, after the
+// all-reduce, scatter the per-sample mean back.  Two launches replace the dozen small ones of
+// cat / mul / fill / div / where.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void plc_dp_pack_kernel(const OptTable tb, float* flat, float n_local, const float* guard,
+                                                          float* tail) {
+    const long long total = tb.start[tb.n];
+    const long long base = (long long)blockIdx.x * OPT_ELEMS_PER_BLOCK;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const long long e = base + threadIdx.x + j * 256;
+        if (e < total) {
+            const int k = plc_opt_find(tb, e);
+            flat[e] = tb.grad[k][e - tb.start[k]] * n_local;
+        }
+    }
+    if (tail && blockIdx.x == 0 && threadIdx.x == 0) {
+        const float gv = guard ? *guard : 0.0f;
+        tail[0] = gv != gv ? 1.0f : 0.0f;
+        tail[1] = n_local;
+    }
+}
+
+__global__ __launch_bounds__(256) void plc_dp_unpack_kernel(const OptTable tb, const float* flat, const float* tail,
+                                                            const float* guard_in, float* guard_out) {
+    const float count = tail[1];
+    const long long total = tb.start[tb.n];
+    const long long base = (long long)blockIdx.x * OPT_ELEMS_PER_BLOCK;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const long long e = base + threadIdx.x + j * 256;
+        if (e < total) {
+            const int k = plc_opt_find(tb, e);
+            tb.grad[k][e - tb.start[k]] = flat[e] / count;
+        }
+    }
+    if (guard_out && blockIdx.x == 0 && threadIdx.x == 0) {
+        const float f = tail[0];
+        *guard_out = (f > 0.0f || f != f) ? __builtin_nanf("") : (guard_in ? *guard_in : 0.0f);
+    }
+}

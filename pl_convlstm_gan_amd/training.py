@@ -108,6 +108,47 @@ def any_rank_true(flag: torch.Tensor, group=None) -> bool:
     return bool(f.item() > 0)
 
 
+def exchange_grads_device(params, n_local: int, guard: Optional[torch.Tensor] = None, group=None) -> Optional[torch.Tensor]:
+    """The step's one collective for GPU gradients, as two library launches around the all-reduce
+    (``plc_dp_pack_grads`` / ``plc_dp_unpack_grads``): every rank's gradients, scaled by its sample count,
+    travel in one flat buffer whose last two elements are this rank's NaN flag (``guard`` is NaN) and its
+    sample count; afterwards every ``p.grad`` holds the per-sample mean over the global batch.  Returns the
+    guard for the optimizer's guarded step -- NaN when the loss of ANY rank was NaN, so that all ranks skip
+    the same batches -- or None when no guard was given.  Parameters without a gradient are left out (every
+    rank runs the same graph, so they agree on which those are)."""
+    import ctypes as C
+
+    from . import _lib
+    L = _lib.lib()
+    ps = [p for p in params if p.grad is not None]
+    if not ps:
+        return guard
+    dev = ps[0].grad.device
+    table = (_lib.OptTensor * len(ps))()
+    total = 0
+    for k, p in enumerate(ps):
+        g = p.grad
+        if not g.is_cuda or g.dtype != torch.float32 or not g.is_contiguous():
+            raise RuntimeError("exchange_grads_device: gradients must be contiguous fp32 GPU tensors")
+        table[k].grad, table[k].numel = g.data_ptr(), g.numel()
+        total += g.numel()
+    flat = torch.empty(total + 2, dtype=torch.float32, device=dev)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    g_in = None
+    if guard is not None:
+        g_in = guard.detach().reshape(-1)[:1].float().contiguous()
+    # (a group of one rank: the weights cancel, and 1 keeps the gradients bit-identical to a step without a group)
+    weight = float(n_local) if _world(group) > 1 else 1.0
+    _lib.check(L.plc_dp_pack_grads(table, len(ps), flat.data_ptr(), total + 2, weight,
+                                   g_in.data_ptr() if g_in is not None else None, stream), "plc_dp_pack_grads")
+    _all_reduce(flat, dist.ReduceOp.SUM, group)
+    g_out = torch.empty_like(g_in) if g_in is not None else None
+    _lib.check(L.plc_dp_unpack_grads(table, len(ps), flat.data_ptr(), total + 2,
+                                     g_in.data_ptr() if g_in is not None else None,
+                                     g_out.data_ptr() if g_out is not None else None, stream), "plc_dp_unpack_grads")
+    return g_out
+
+
 def clip_flat_(flat: torch.Tensor, max_norm: float) -> torch.Tensor:
     """torch.nn.utils.clip_grad_norm_ on the flat buffer: scale by min(1, max_norm/(||g||+1e-6)).
     Returns the pre-clip norm (0-dim tensor, no host sync)."""
@@ -145,23 +186,13 @@ def train_step(model, loss_module, optimizer, rain_lr, dem, lu, s_coords, s_valu
         return loss, loss_dict, fake_hr, True
     loss.backward()
     params = list(clip_params if clip_params is not None else model.parameters())
-    if _dp_active(group) or not fused:
+    if _dp_active(group) and fused and rain_lr.is_cuda:
+        # device mode: this rank's NaN flag rides in the gradient buffer, so the step has ONE collective
+        guard = exchange_grads_device(params, int(rain_lr.shape[0]), guard, group)
+    elif _dp_active(group) or not fused:
         bucket = GradBucket(params)
-        multi = _dp_active(group)
-        # device mode: this rank's NaN flag rides in the gradient bucket, so the step has ONE
-        # collective; its mean is > 0 iff the loss of any rank is NaN, which poisons every rank's guard.
-        # The last element is the spare one of the sample-weighted mean (this rank's sample count).
-        share_flag = on_device and multi
-        extra = []
-        if share_flag:
-            extra.append(torch.isnan(guard).to(torch.float32).reshape(1))
-        if multi:
-            extra.append(torch.zeros(1, dtype=torch.float32, device=rain_lr.device))
-        flat = bucket.gather(torch.cat(extra) if extra else None)
+        flat = bucket.gather(torch.zeros(1, dtype=torch.float32, device=rain_lr.device) if _dp_active(group) else None)
         all_reduce_weighted_mean_(flat, int(rain_lr.shape[0]), group)
-        if share_flag:
-            flag = bucket.extra()[:1]
-            guard = torch.where((flag > 0) | torch.isnan(flag), torch.full_like(guard, float("nan")), guard)
         if not fused:
             clip_flat_(flat[:sum(bucket.sizes)], max_norm)
         bucket.scatter()

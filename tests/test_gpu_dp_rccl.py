@@ -62,3 +62,54 @@ def test_one_rank_rccl_group_runs_the_exchange(gpu):
     for (_, a), (_, b) in zip(plain, grouped):
         assert torch.equal(a, b)
     assert torch.equal(grouped[0][1], grouped[1][1]) and not torch.equal(grouped[1][1], grouped[2][1])
+
+
+def test_pack_and_unpack_of_the_gradient_buffer(gpu):
+    """The two library launches around the all-reduce against the torch operators they replace (multiply by the
+    rank's sample count, SUM over ranks, divide by the total count; NaN flag and count in the two trailing
+    elements).  The SUM of a second rank is played by adding a second packed buffer, as the collective would."""
+    import ctypes as C
+    from pl_convlstm_gan_amd import _lib
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(5)
+    shapes = [(16, 3, 3, 3), (16,), (64, 32, 3, 3), (64,), (1, 32, 3, 3), (1,)] + [(7,)] * 50     # > 48 tensors: two table chunks
+    st = torch.cuda.current_stream(gpu).cuda_stream
+
+    def rank_grads(seed):
+        gg = torch.Generator().manual_seed(seed)
+        return [torch.randn(s, generator=gg).to(gpu) for s in shapes]
+
+    def table_of(grads):
+        tb = (_lib.OptTensor * len(grads))()
+        for k, t in enumerate(grads):
+            tb[k].grad, tb[k].numel = t.data_ptr(), t.numel()
+        return tb
+
+    total = sum(t.numel() for t in rank_grads(0))
+    for nan_rank in (None, 1):
+        ga, gb = rank_grads(1), rank_grads(2)
+        ref_a = [t.clone() for t in ga]
+        ref_b = [t.clone() for t in gb]
+        loss_a = torch.tensor([0.25], device=gpu)
+        loss_b = torch.tensor([float("nan") if nan_rank == 1 else 0.5], device=gpu)
+        fa = torch.empty(total + 2, device=gpu)
+        fb = torch.empty(total + 2, device=gpu)
+        ta, tb = table_of(ga), table_of(gb)
+        _lib.check(L.plc_dp_pack_grads(ta, len(ga), fa.data_ptr(), total + 2, 3.0, loss_a.data_ptr(), st), "pack a")
+        _lib.check(L.plc_dp_pack_grads(tb, len(gb), fb.data_ptr(), total + 2, 5.0, loss_b.data_ptr(), st), "pack b")
+        assert torch.equal(fa[:total], torch.cat([t.reshape(-1) for t in ref_a]) * 3.0)
+        assert fa[total:].tolist() == [0.0, 3.0]
+        assert fb[total:].tolist() == [1.0 if nan_rank == 1 else 0.0, 5.0]
+        summed = fa + fb                                           # what all_reduce(SUM) leaves on both ranks
+        out_a = torch.empty(1, device=gpu)
+        _lib.check(L.plc_dp_unpack_grads(ta, len(ga), summed.data_ptr(), total + 2, loss_a.data_ptr(), out_a.data_ptr(), st), "unpack")
+        want = (torch.cat([t.reshape(-1) for t in ref_a]) * 3.0 + torch.cat([t.reshape(-1) for t in ref_b]) * 5.0) / 8.0
+        got = torch.cat([t.reshape(-1) for t in ga])
+        assert torch.equal(got, want)
+        if nan_rank is None:
+            assert float(out_a) == 0.25
+        else:
+            assert torch.isnan(out_a).all()                        # the other rank's NaN poisons this rank's guard
+    # a wrong buffer length is refused
+    with pytest.raises(ValueError):
+        _lib.check(L.plc_dp_pack_grads(ta, len(ga), fa.data_ptr(), total + 1, 3.0, None, st), "pack")
