@@ -254,9 +254,13 @@ static int ensure_lds_limit(const void* kern, int lds, bool (&done)[64]) {
 // one on the caller's stream and one here (batch elements are independent), so that one half's
 // memory-bound phases run beside the other half's arithmetic.  Fork and join are event record / wait
 // pairs, which a stream capture follows.
+// `side` is a third stream for work nothing in the recurrences waits for: the forward of the two attention
+// branches (t-invariant) runs beside the stem and the first cell launches; in the backward pass the weight
+// gradients of the two post convs and the branches' whole backward run beside the data-gradient chain and
+// the BPTT loop, and are joined before the slab reduction.
 struct PlcAux {
-    hipStream_t stream;
-    hipEvent_t ev[3];
+    hipStream_t stream, side;
+    hipEvent_t ev[3], sev[6];
 };
 static int plc_aux(PlcAux** out) {
     static PlcAux aux[64];
@@ -265,7 +269,9 @@ static int plc_aux(PlcAux** out) {
     if (dev < 0) return plc_fail(PLC_EHIP, "no current device");
     if (!made[dev]) {
         PLC_HIP(hipStreamCreateWithFlags(&aux[dev].stream, hipStreamNonBlocking));
+        PLC_HIP(hipStreamCreateWithFlags(&aux[dev].side, hipStreamNonBlocking));
         for (int k = 0; k < 3; ++k) PLC_HIP(hipEventCreateWithFlags(&aux[dev].ev[k], hipEventDisableTiming));
+        for (int k = 0; k < 6; ++k) PLC_HIP(hipEventCreateWithFlags(&aux[dev].sev[k], hipEventDisableTiming));
         made[dev] = true;
     }
     *out = &aux[dev];
@@ -342,6 +348,16 @@ static int launch_conv(ConvArgs a, int n_img, int n_mgroups, hipStream_t st) {
     // (single-M-tile convs whose staging is not plain DMA were measured faster with 8-row tiles)
     if (t16 >= 512 && !(NMT == 1 && STAGE != STAGE_CB8)) return launch_conv_th<NCB0, NCB1, NMT, KS, STAGE, EPI, 16>(a, n_img, n_mgroups, st);
     return launch_conv_th<NCB0, NCB1, NMT, KS, STAGE, EPI, 8>(a, n_img, n_mgroups, st);
+}
+
+// Whether the attention branches of a rollout with `out_px` = B * out_H * out_W output pixels per time step go
+// to the side stream.  Below ~1e5 pixels a step is bound by launches, not by the GPU, and the fork / join only
+// adds to that (15 x 12 -> 120 x 96, B = 8: +3 %; 64 x 64, B = 2: +15 % on the train step); above, the branches'
+// small launches disappear behind the recurrence (256 x 256, B = 4: forward -2.5 %, train step -1.5 %; x8
+// upsampling to 256 x 256: forward -9 %).  PLC_NO_SIDE_STREAM=1 keeps them on the caller's stream (measurements).
+static bool plc_use_side_stream(long long out_px) {
+    static const bool off = [] { const char* e = getenv("PLC_NO_SIDE_STREAM"); return e && *e && *e != '0'; }();
+    return !off && out_px >= (1ll << 17);
 }
 
 // Debugging / measurement switch: PLC_NO_ROLLING=1 keeps the tile-at-a-time kernels where a rolling-window
@@ -978,7 +994,16 @@ extern "C" int plc_generator_rollout_fwd(const plc_rollout_desc* d, void* stream
     if ((rc = pack_batch_flush(&batch, st))) return rc;
 
     // ---- t-invariant gates: sigmoid(conv1x1(relu(conv3x3(aux)))) for DEM and land use, multiplied
+    // Nothing before the gated post conv reads them, so they run on the side stream, beside the stem and the
+    // first cell launches (six small launches over B images that would otherwise hold the chip alone).
+    PlcAux* side_aux = nullptr;
+    if (fast && plc_use_side_stream((long long)B * ohw)) {
+        if ((rc = plc_aux(&side_aux))) return rc;
+        PLC_HIP(hipEventRecord(side_aux->sev[0], (hipStream_t)stream));          // the packed weights are ready
+        PLC_HIP(hipStreamWaitEvent(side_aux->side, side_aux->sev[0], 0));
+    }
     {
+        hipStream_t st = side_aux ? side_aux->side : (hipStream_t)stream;        // (this block's stream)
         const long long tot_d = (long long)B * 1 * ohw, tot_l = (long long)B * cdiv(L, 8) * ohw;
         hipLaunchKernelGGL(plc_resize_nchw_to_cb8_kernel, dim3(ew_grid(tot_d)), dim3(256), 0, st, d->dem,
                            (uint4*)(ws + p.dem_hr), B, 1, d->dem_H, d->dem_W, oH, oW, 0,
@@ -1032,6 +1057,7 @@ extern "C" int plc_generator_rollout_fwd(const plc_rollout_desc* d, void* stream
         if ((rc = fast ? launch_conv<2, 0, 1, 1, STAGE_CB8, EPI_ACT_CB8>(a, B, 1, st)
                        : launch_convg<1, STAGE_CB8, EPI_ACT_CB8>(a, mcb, 0, cdiv(C2, 32), B, st)))
             return rc;
+        if (side_aux) PLC_HIP(hipEventRecord(side_aux->sev[1], st));
     }
 
     // ---- stem over all T*B frames: x_t = relu(conv3x3([rain, row, col])) ------------------
@@ -1204,6 +1230,7 @@ extern "C" int plc_generator_rollout_fwd(const plc_rollout_desc* d, void* stream
         PLC_HIP(hipGetLastError());
         feat = ws + p.fin;
     }
+    if (side_aux) PLC_HIP(hipStreamWaitEvent(st, side_aux->sev[1], 0));           // the gate maps are ready
     {
         ConvArgs a = conv_args(oH, oW, B);
         a.src0 = tens(feat, (C2 / 8) * ohw * 16, (long long)B * (C2 / 8) * ohw * 16);

@@ -36,6 +36,7 @@ struct SlabArena {
     size_t size, used;
     FinalizeTable tb;
     int blocks;
+    bool no_early_flush;     // launches of this pass run on more than one stream: reducing before the join would race
 };
 static void arena_begin(SlabArena* ar, void* base, size_t size) {
     ar->base = (char*)base;
@@ -43,6 +44,7 @@ static void arena_begin(SlabArena* ar, void* base, size_t size) {
     ar->used = 0;
     ar->tb.n = 0;
     ar->blocks = 0;
+    ar->no_early_flush = false;
 }
 static int arena_flush(SlabArena* ar, hipStream_t st) {
     if (ar->tb.n > 0) {
@@ -65,6 +67,7 @@ static int launch_wgrad(ConvArgs in, PlcTensor dz, int mcb_valid, int n_img, Sla
         return plc_fail(PLC_EUNSUPPORTED, "wgrad: the plain CB8 staging does not load a dz mask");
     const size_t need = wgrad_slab_bytes<NCB0, NCB1, MT, KS>();
     if (ar->used + need > ar->size || ar->tb.n == FINALIZE_MAX_JOBS) {
+        if (ar->no_early_flush) return plc_fail(PLC_EWORKSPACE, "wgrad: slab arena full before the streams were joined");
         int rc = arena_flush(ar, st);
         if (rc) return rc;
     }
@@ -125,6 +128,7 @@ static int launch_wgrad_cout1(PlcTensor x, PlcTensor dy, int n_in, int H, int W,
                               float* db, hipStream_t st) {
     const size_t need = wgrad_cout1_slab_bytes();
     if (ar->used + need > ar->size || ar->tb.n == FINALIZE_MAX_JOBS) {
+        if (ar->no_early_flush) return plc_fail(PLC_EWORKSPACE, "wgrad: slab arena full before the streams were joined");
         int rc = arena_flush(ar, st);
         if (rc) return rc;
     }
@@ -587,6 +591,16 @@ extern "C" int plc_generator_rollout_bwd(const plc_rollout_desc* d, const plc_ro
     SlabArena arena;
     arena_begin(&arena, wb + bp.slab, bp.slab_bytes);
     SlabArena* const slab = &arena;
+    // Weight gradients are leaves: nothing but the final slab reduction reads them.  With the instantiated widths
+    // (whose arena holds every slab of the pass, so no reduction happens early) those of the two post convs and
+    // the attention branches' whole backward go to the side stream and run beside the data-gradient chain and the
+    // BPTT loop.  side_aux != nullptr: that is the case.
+    PlcAux* side_aux = nullptr;
+    if (widths_fast(d->C1, d->C2) && plc_use_side_stream((long long)d->B * d->out_H * d->out_W)) {
+        if ((rc = plc_aux(&side_aux))) return rc;
+        arena.no_early_flush = true;
+    }
+    hipStream_t const ss = side_aux ? side_aux->side : (hipStream_t)stream;       // the leaves' stream
     const float* bpk0 = (const float*)(wb + bp.bpk0);
     const int mcb = cdiv(C2 / 2, 8);
     const long long fimg = (C2 / 8) * ohw * 16;   // one C2-channel image at output resolution
@@ -611,12 +625,19 @@ extern "C" int plc_generator_rollout_bwd(const plc_rollout_desc* d, const plc_ro
             if ((rc = packT(d->up_w[k], bp.upT[k], 4 * C2, C2, 0, 3, 2, gen))) return rc;
         if ((rc = pack_batch_flush(&batch, st))) return rc;
     }
+    if (side_aux) {
+        PLC_HIP(hipEventRecord(side_aux->sev[4], st));
+        PLC_HIP(hipStreamWaitEvent(ss, side_aux->sev[4], 0));
+    }
 
     // ---- output convs -------------------------------------------------------------------------
     const PlcTensor gout = tens(g->grad_out, (long long)T * ohw * 4, ohw * 4);   // n = t*B + b -> grad_out[b][t]
     {
         // the one-output-channel conv: its weight gradient streams the conv input once on the vector
         // ALUs and reads the loss gradient in fp32 as it is
+        // (on the caller's stream: beside the conv that follows, on two queues, this kernel's sums were observed
+        // to vary from run to run in the last digits although the two share no written byte; alone on its
+        // stream, or beside any of the later kernels, they do not)
         if ((rc = launch_wgrad_cout1(tens(wf + fp.p0, 4 * ohw * 16, (long long)B * 4 * ohw * 16), gout, B, oH, oW, NI,
                                      slab, g->post2_w, g->post2_b, st)))
             return rc;
@@ -630,14 +651,18 @@ extern "C" int plc_generator_rollout_bwd(const plc_rollout_desc* d, const plc_ro
         a.bpk = bpk0;
         a.ncb_out = 4;
         if ((rc = launch_conv<1, 0, 1, 3, STAGE_F32_1CH, EPI_ACT_CB8>(a, NI, 1, st))) return rc;
+        if (side_aux) {                  // d_pre0 is ready for the gated post conv's weight gradient
+            PLC_HIP(hipEventRecord(side_aux->sev[2], st));
+            PLC_HIP(hipStreamWaitEvent(ss, side_aux->sev[2], 0));
+        }
 
         in = conv_args(oH, oW, B);
         in.src0 = tens(wf + fp.fin, fimg, (long long)B * fimg);
         in.gate = tens(wf + fp.gate, fimg, 0);
         if ((rc = fast ? launch_wgrad<4, 0, 1, 3, STAGE_CB8_GATED>(in, tens(wb + bp.d_pre0, 4 * ohw * 16, (long long)B * 4 * ohw * 16),
-                                                                   4, NI, slab, g->post0_w, g->post0_b, 32, C2, 0, st)
+                                                                   4, NI, slab, g->post0_w, g->post0_b, 32, C2, 0, ss)
                        : wgrad_chunked<4, 1, 3, STAGE_CB8_GATED>(in, C2, 0, tens(wb + bp.d_pre0, 4 * ohw * 16, (long long)B * 4 * ohw * 16),
-                                                                 32, NI, slab, g->post0_w, g->post0_b, st)))
+                                                                 32, NI, slab, g->post0_w, g->post0_b, ss)))
             return rc;
         a = conv_args(oH, oW, B);
         a.src0 = tens(wb + bp.d_pre0, 4 * ohw * 16, (long long)B * 4 * ohw * 16);
@@ -672,6 +697,13 @@ extern "C" int plc_generator_rollout_bwd(const plc_rollout_desc* d, const plc_ro
             const float* w0; float *g0w, *g0b, *g2w, *g2b;
             int cin;
         };
+        // The branches end in parameter gradients only (the aux maps need none): on the leaves' stream, after the
+        // gate backward's outputs.
+        hipStream_t st = ss;
+        if (side_aux) {
+            PLC_HIP(hipEventRecord(side_aux->sev[3], (hipStream_t)stream));
+            PLC_HIP(hipStreamWaitEvent(ss, side_aux->sev[3], 0));
+        }
         const Branch br[2] = {
             {bp.d_lu_pre, bp.d_lu_mid, fp.lu_mid, fp.lu_hr, bp.lu2T, d->lu0_w, g->lu0_w, g->lu0_b, g->lu2_w, g->lu2_b, L},
             {bp.d_dem_pre, bp.d_dem_mid, fp.dem_mid, fp.dem_hr, bp.dem2T, d->dem0_w, g->dem0_w, g->dem0_b, g->dem2_w, g->dem2_b, 1},
@@ -736,12 +768,16 @@ extern "C" int plc_generator_rollout_bwd(const plc_rollout_desc* d, const plc_ro
         hipLaunchKernelGGL(plc_pixel_unshuffle_mask_kernel, dim3(ew_grid((long long)NI * (C2 / 8) * khw)), dim3(256),
                            0, st, cur, (const char*)(wf + fp.up_out[k]), wb + bp.d_conv[k], NI, C2, kh, kw);
         PLC_HIP(hipGetLastError());
+        if (side_aux) {                  // d_conv[k] is ready for the block's weight gradient (a leaf)
+            PLC_HIP(hipEventRecord(side_aux->sev[3], st));
+            PLC_HIP(hipStreamWaitEvent(ss, side_aux->sev[3], 0));
+        }
         ConvArgs in = conv_args(kh, kw, NI);
         in.src0 = tens(in_k, (C2 / 8) * khw * 16, 0);
         if ((rc = fast ? launch_wgrad<4, 0, 4, 3, STAGE_CB8>(in, tens(wb + bp.d_conv[k], (4 * C2 / 8) * khw * 16, 0), 4 * C2 / 8,
-                                                             NI, slab, g->up_w[k], g->up_b[k], 4 * C2, C2, 0, st)
+                                                             NI, slab, g->up_w[k], g->up_b[k], 4 * C2, C2, 0, ss)
                        : wgrad_chunked<4, 4, 3, STAGE_CB8>(in, C2, 0, tens(wb + bp.d_conv[k], (4 * C2 / 8) * khw * 16, 0), 4 * C2,
-                                                           NI, slab, g->up_w[k], g->up_b[k], st)))
+                                                           NI, slab, g->up_w[k], g->up_b[k], ss)))
             return rc;
         ConvArgs a = conv_args(kh, kw, NI);
         a.src0 = tens(wb + bp.d_conv[k], (4 * C2 / 8) * khw * 16, 0);
@@ -796,7 +832,9 @@ extern "C" int plc_generator_rollout_bwd(const plc_rollout_desc* d, const plc_ro
     };
     const bool skew = fast && T > 1 && !plc_no_rolling() && !plc_no_pairing();
     static const bool no_split = [] { const char* e = getenv("PLC_NO_BWD_SPLIT"); return e && *e && *e != '0'; }();
-    if (skew && !no_split && !plc_fused_pw() && B >= 2) {
+    // (only where a launch is long enough to pay for the second queue: on the small recurrence grids the step is
+    // launch-bound and the two chains cost 3 % (32 x 32, B = 4) to 15 % (15 x 12, B = 8) of the train step)
+    if (skew && !no_split && !plc_fused_pw() && B >= 2 && (long long)B * hw >= (1ll << 17)) {
         // The batch elements are independent, and the recurrence alternates an HBM-bound launch (pointwise
         // passes) with an MFMA-bound one (data-gradient convs).  The two halves of the batch therefore run as
         // two chains on two streams, the second one launch behind the first: one half's pointwise passes
@@ -909,5 +947,9 @@ extern "C" int plc_generator_rollout_bwd(const plc_rollout_desc* d, const plc_ro
                          g->cell1_b, C1, C1, H, W, st, true)))
         return rc;
     // ---- every conv's slabs -> parameter gradients, one launch ----------------------------------
+    if (side_aux) {                      // join: every leaf has written its slabs
+        PLC_HIP(hipEventRecord(side_aux->sev[5], ss));
+        PLC_HIP(hipStreamWaitEvent(st, side_aux->sev[5], 0));
+    }
     return arena_flush(&arena, st);
 }

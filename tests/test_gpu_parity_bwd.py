@@ -189,12 +189,13 @@ def _digest_run(env_extra):
         f"sys.path.insert(0, {root!r})\n"
         "from pl_convlstm_gan_amd import Generator\n"
         "gpu = torch.device('cuda:0')\n"
-        "for (B, T, H, W, seed) in [(2, 4, 37, 45, 8), (3, 3, 16, 70, 11), (1, 3, 64, 64, 5), (4, 2, 256, 256, 3)]:\n"
+        "for (B, T, H, W, seed, s) in [(2, 4, 37, 45, 8, 1), (3, 3, 16, 70, 11, 1), (1, 3, 64, 64, 5, 1), (4, 2, 256, 256, 3, 1),\n"
+        "                              (2, 2, 32, 32, 9, 8)]:\n"
         "    torch.manual_seed(seed)\n"
-        "    m = Generator(hidden_dims=[16, 32], lu_channels=5, scale_factor=1).to(gpu)\n"
+        "    m = Generator(hidden_dims=[16, 32], lu_channels=5, scale_factor=s).to(gpu)\n"
         "    g = torch.Generator().manual_seed(seed + 1)\n"
         "    rain = 10 * torch.rand(B, T, 1, H, W, generator=g) * (torch.rand(B, T, 1, H, W, generator=g) > 0.7)\n"
-        "    dem, lu = torch.rand(B, 1, H, W, generator=g), torch.rand(B, 5, H, W, generator=g)\n"
+        "    dem, lu = torch.rand(B, 1, H * s, W * s, generator=g), torch.rand(B, 5, H * s, W * s, generator=g)\n"
         "    out = m(rain.to(gpu), dem.to(gpu), lu.to(gpu))\n"
         "    (out * (torch.rand(out.shape, generator=g) + 0.5).to(gpu)).sum().backward()\n"
         "    h = hashlib.sha256(out.detach().cpu().numpy().tobytes())\n"
@@ -214,10 +215,12 @@ def test_kernel_selection_switches_do_not_change_a_bit(gpu):
     recurrences, the gated post conv walking its tiles time-innermost), the
     tile-at-a-time convs, the unpaired loop, the single chains, the image-major gated conv and
     the data-gradient convs that run the pointwise backward themselves (PLC_FUSED_PW=1) must give the
-    same digest of the output and of every parameter gradient, at ragged shapes included (the last shape is
-    large enough for the forward recurrence to run as two chains)."""
+    same digest of the output and of every parameter gradient, at ragged shapes included (the last two shapes
+    are large enough for the forward recurrence to run as two chains and for the side stream -- attention
+    branches and leaf weight gradients beside the recurrences -- to be used, at scale 1 and through three
+    upsample blocks)."""
     base = _digest_run({})
-    assert len(base) == 4
+    assert len(base) == 5
     for env in ({"PLC_NO_ROLLING": "1"}, {"PLC_NO_PAIRING": "1"}, {"PLC_FUSED_PW": "1"}, {"PLC_NO_BWD_SPLIT": "1"},
-                {"PLC_NO_FWD_SPLIT": "1"}, {"PLC_NO_GATED_TINNER": "1"}):
+                {"PLC_NO_FWD_SPLIT": "1"}, {"PLC_NO_GATED_TINNER": "1"}, {"PLC_NO_SIDE_STREAM": "1"}):
         assert _digest_run(env) == base, env
