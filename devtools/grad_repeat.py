@@ -15,7 +15,7 @@ dem = torch.rand(B, 1, H * s, W * s, generator=g)
 lu = torch.rand(B, 5, H * s, W * s, generator=g)
 wgt = (torch.rand(B, T, 1, H, W, generator=g) + 0.5).to(gpu)
 ref = None
-for rep in range(4):
+for rep in range(int(os.environ.get('REPS', '4'))):
     m.zero_grad()
     out = m(rain.to(gpu), dem.to(gpu), lu.to(gpu))
     (out * wgt).sum().backward()

@@ -7,12 +7,19 @@
  * Conventions
  *   - every function returns 0 on success, a negative PLC_E* code on failure; the message of
  *     the last failure on the calling thread is available from plc_last_error();
- *   - the caller owns every buffer (workspaces included); the library allocates nothing and is
- *     re-entrant; the only device state it keeps is the fixed staging array of
- *     plc_convlstm_cell_fwd_noalloc (see there), the only host state a per-device cache of immutable
- *     facts (CU count, "LDS limit raised" flags, that array's address);
+ *   - the caller owns every buffer (workspaces included); the library allocates no device memory.
+ *     The only device state it keeps is the fixed staging array of plc_convlstm_cell_fwd_noalloc (see
+ *     there); the host state is a per-device cache of immutable facts (CU count, "LDS limit raised"
+ *     flags, that array's address) and, created on the first rollout call on a device and kept, two
+ *     auxiliary streams with the events of their forks and joins;
  *   - every call is asynchronous on the hipStream_t passed as `stream` (a `void*` here so the
- *     header needs no HIP include); nothing synchronises;
+ *     header needs no HIP include); nothing synchronises with the host.  The two rollout calls may put
+ *     part of their work on the auxiliary streams (independent halves of the batch, work that nothing
+ *     in the recurrence waits for): it is forked from `stream` by an event and joined back into it
+ *     before the call's last launch, so for the caller everything is ordered on `stream` as if it
+ *     had run there, and a stream capture of the call is valid.  Rollout calls on one device share the
+ *     auxiliary streams: calls issued from several host threads at once are serialised there (their
+ *     results are unaffected);
  *   - tensors crossing the boundary are fp32, NCHW-contiguous, 16-byte aligned, exactly as the
  *     reference's modules take and return them.  Internally activations are kept as bf16 in a
  *     channel-blocked layout ("CB8": [image][C/8][H][W][8]) with fp32 accumulation and an fp32

@@ -7,6 +7,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <mutex>
+
 #include "../../include/plconvlstm.h"
 #include "plc_conv_kernel.h"
 #include "plc_convg_kernel.h"
@@ -258,6 +260,10 @@ static int ensure_lds_limit(const void* kern, int lds, bool (&done)[64]) {
 // branches (t-invariant) runs beside the stem and the first cell launches; in the backward pass the weight
 // gradients of the two post convs and the branches' whole backward run beside the data-gradient chain and
 // the BPTT loop, and are joined before the slab reduction.
+// The streams and events are shared by every rollout call on the device, and a wait takes the event's latest
+// record AT THE TIME OF THE CALL: the rollout entry points therefore hold plc_aux_mutex while they enqueue, so
+// that calls from several host threads cannot pair one call's wait with another call's record.
+static std::mutex plc_aux_mutex;
 struct PlcAux {
     hipStream_t stream, side;
     hipEvent_t ev[3], sev[6];
@@ -949,6 +955,7 @@ extern "C" size_t plc_generator_workspace_offset(const plc_rollout_desc* d, cons
 }
 
 extern "C" int plc_generator_rollout_fwd(const plc_rollout_desc* d, void* stream) {
+    std::lock_guard<std::mutex> aux_lock(plc_aux_mutex);
     RolloutPlan p;
     int rc = rollout_plan(d, &p);
     if (rc) return rc;
