@@ -178,3 +178,45 @@ def test_single_launch_recurrence_vs_oracle(gpu, monkeypatch, shape):
     (emu * wgt).sum().backward()
     for k, gr in g_a.items():
         assert relmax(gr.cpu(), leaf[k].grad) <= 3e-2 and rel_l2(gr.cpu(), leaf[k].grad) <= 3e-2, k
+
+
+def test_rollouts_from_two_host_threads(gpu):
+    """Two host threads, each with its own model, input and stream, call the rollout at the same time at a size
+    where the library forks work onto its per-device auxiliary streams (whose events all calls share): every
+    result must equal the one the same call gives alone."""
+    import threading
+    from pl_convlstm_gan_amd import Generator
+    jobs = []
+    for seed in (1, 2):
+        torch.manual_seed(seed)
+        m = Generator(hidden_dims=[16, 32], lu_channels=5, scale_factor=1).to(gpu)
+        g = torch.Generator().manual_seed(seed + 10)
+        B, T, H, W = 4, 3, 256, 256
+        rain = (10 * torch.rand(B, T, 1, H, W, generator=g) * (torch.rand(B, T, 1, H, W, generator=g) > 0.7)).to(gpu)
+        dem, lu = torch.rand(B, 1, H, W, generator=g).to(gpu), torch.rand(B, 5, H, W, generator=g).to(gpu)
+        with torch.no_grad():
+            alone = m(rain, dem, lu).clone()
+        jobs.append((m, rain, dem, lu, alone))
+    torch.cuda.synchronize()
+    results, errors = [None, None], []
+
+    def work(k):
+        try:
+            m, rain, dem, lu, _ = jobs[k]
+            s = torch.cuda.Stream(device=gpu)
+            with torch.cuda.stream(s), torch.no_grad():
+                outs = [m(rain, dem, lu).clone() for _ in range(6)]
+            s.synchronize()
+            results[k] = outs
+        except Exception as e:      # noqa: BLE001  (reported by the assertion below)
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for k in range(2):
+        for out in results[k]:
+            assert torch.equal(out, jobs[k][4])
