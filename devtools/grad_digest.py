@@ -8,7 +8,7 @@ from pl_convlstm_gan_amd import Generator
 
 gpu = torch.device("cuda:0")
 for (B, T, H, W, s, seed) in [(4, 10, 256, 256, 1, 3), (2, 10, 128, 128, 1, 21), (2, 3, 16, 16, 1, 5), (1, 4, 24, 40, 1, 7),
-                              (1, 3, 37, 45, 1, 8), (3, 2, 9, 70, 1, 11), (1, 2, 32, 32, 8, 9), (2, 2, 15, 12, 8, 13), (2, 3, 32, 32, 8, 15)]:
+                              (1, 3, 37, 45, 1, 8), (3, 2, 9, 70, 1, 11), (1, 2, 32, 32, 8, 9), (2, 2, 15, 12, 8, 13), (2, 3, 32, 32, 8, 15), (8, 2, 128, 128, 1, 17)]:
     torch.manual_seed(seed)
     m = Generator(hidden_dims=[16, 32], lu_channels=5, scale_factor=s).to(gpu)
     g = torch.Generator().manual_seed(seed + 1)

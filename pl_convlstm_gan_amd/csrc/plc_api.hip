@@ -1148,7 +1148,7 @@ extern "C" int plc_generator_rollout_fwd(const plc_rollout_desc* d, void* stream
         }
         static const bool no_fwd_split = [] { const char* e = getenv("PLC_NO_FWD_SPLIT"); return e && *e && *e != '0'; }();
         const long long t16_all = (long long)B * cdiv(H, 16) * cdiv(W, 32);
-        if (!persistent && fast && T > 1 && !plc_no_pairing() && !no_fwd_split && B >= 2 && t16_all >= 512) {
+        if (!persistent && fast && T > 1 && !plc_no_pairing() && !no_fwd_split && B >= 2 && (long long)B * hw >= (1ll << 17)) {
             // Two half-batch chains on two streams, the second one launch behind the first (as the backward
             // recurrence does): a cell launch starts with a burst of weight and halo-tile fetches and ends with
             // a drain, during which the other chain's workgroups have the matrix pipes.  Same kernels, same
@@ -1166,15 +1166,22 @@ extern "C" int plc_generator_rollout_fwd(const plc_rollout_desc* d, void* stream
             // stage k of a chain: 0 = cell 1 (0); k = 1 .. T-1: cell 2 (k-1) + cell 1 (k); T = cell 2 (T-1)
             auto stage = [&](int h, int k) -> int {
                 const int nb = nbh[h];
+                // (the tile height the whole batch would get: launch_conv's rule)
                 if (k == 0) {
                     ConvArgs a = half(cell1(0), h);
-                    return save ? launch_conv_th<2, 2, 2, 3, STAGE_CB8, EPI_LSTM_SAVE, 16>(a, nb, 1, sh[h])
-                                : launch_conv_th<2, 2, 2, 3, STAGE_CB8, EPI_LSTM, 16>(a, nb, 1, sh[h]);
+                    if (t16_all >= 512)
+                        return save ? launch_conv_th<2, 2, 2, 3, STAGE_CB8, EPI_LSTM_SAVE, 16>(a, nb, 1, sh[h])
+                                    : launch_conv_th<2, 2, 2, 3, STAGE_CB8, EPI_LSTM, 16>(a, nb, 1, sh[h]);
+                    return save ? launch_conv_th<2, 2, 2, 3, STAGE_CB8, EPI_LSTM_SAVE, 8>(a, nb, 1, sh[h])
+                                : launch_conv_th<2, 2, 2, 3, STAGE_CB8, EPI_LSTM, 8>(a, nb, 1, sh[h]);
                 }
                 if (k == T) {
                     ConvArgs a = half(cell2(T - 1), h);
-                    return save ? launch_conv_th<2, 4, 4, 3, STAGE_CB8, EPI_LSTM_SAVE, 16>(a, nb, 1, sh[h])
-                                : launch_conv_th<2, 4, 4, 3, STAGE_CB8, EPI_LSTM, 16>(a, nb, 1, sh[h]);
+                    if (t16_all >= 512)
+                        return save ? launch_conv_th<2, 4, 4, 3, STAGE_CB8, EPI_LSTM_SAVE, 16>(a, nb, 1, sh[h])
+                                    : launch_conv_th<2, 4, 4, 3, STAGE_CB8, EPI_LSTM, 16>(a, nb, 1, sh[h]);
+                    return save ? launch_conv_th<2, 4, 4, 3, STAGE_CB8, EPI_LSTM_SAVE, 8>(a, nb, 1, sh[h])
+                                : launch_conv_th<2, 4, 4, 3, STAGE_CB8, EPI_LSTM, 8>(a, nb, 1, sh[h]);
                 }
                 return launch_pair(half(cell2(k - 1), h), half(cell1(k), h), nb, sh[h], B);
             };
