@@ -636,9 +636,7 @@ extern "C" int plc_generator_rollout_bwd(const plc_rollout_desc* d, const plc_ro
     {
         // the one-output-channel conv: its weight gradient streams the conv input once on the vector
         // ALUs and reads the loss gradient in fp32 as it is
-        // (a leaf, but kept on the caller's stream: side by side with the conv that follows, on two queues, this
-        // kernel's sums were observed to vary from run to run in the last digits although the two share no written
-        // byte -- unexplained; launched on the side stream after that conv it was bit-stable and 0.5 % slower)
+        // (a leaf, but on the side stream, beside the conv that follows, it only slows that conv by what it saves)
         if ((rc = launch_wgrad_cout1(tens(wf + fp.p0, 4 * ohw * 16, (long long)B * 4 * ohw * 16), gout, B, oH, oW, NI,
                                      slab, g->post2_w, g->post2_b, st)))
             return rc;

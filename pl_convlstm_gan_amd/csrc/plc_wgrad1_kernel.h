@@ -108,7 +108,16 @@ __global__ __launch_bounds__(256) void plc_wgrad_cout1_kernel(const Wgrad1Args a
 #pragma unroll
                 for (int kx = 0; kx < 3; ++kx) {
                     const float dv = d[2 - ky][2 - kx];
-                    const plc_f32x2 d2 = plc_f32x2{dv, dv};
+                    // The broadcast pair is MATERIALISED (two moves) instead of being left to the instruction's
+                    // operand select.  The compiler otherwise encodes the taps whose dy value sits in the odd
+                    // register of a ds_read2 pair (kx == 1) as v_pk_fma_f32 ... op_sel:[0,1,0], and on the MI355X
+                    // exactly those 96 of the 288 packed FMAs gave sums that varied from run to run (a few
+                    // entries per slab row, 1e-2 relative) whenever a conv kernel ran on the chip at the same
+                    // time -- never alone, never beside a memset, never for the op_sel_hi:[1,0,1] (even
+                    // register) or plain forms.  With the pair in its own registers the kernel is bit-stable
+                    // beside any other kernel and as fast as before (it is bound by its reads).
+                    plc_f32x2 d2 = plc_f32x2{dv, dv};
+                    asm volatile("" : "+v"(d2));
 #pragma unroll
                     for (int j = 0; j < 4; ++j) acc[ky * 3 + kx][j] = __builtin_elementwise_fma(xv[j], d2, acc[ky * 3 + kx][j]);
                 }
