@@ -380,6 +380,16 @@ def main():
             res["step_mfma_frac"] = (3 if args.mode == "train" else 1) * fwd_flop / (dt / args.steps) / (world * PEAK_BF16)
             res["fwd_mfma_frac"] = fwd_flop / (dt_fwd / n_fwd) / (world * PEAK_BF16)
             res["fwd_hbm_frac"] = FWD_BYTES_PER_PX * px * world * B * T / (dt_fwd / n_fwd) / (world * PEAK_HBM)
+        # the train step against the HBM roof by MEASURED traffic: bytes of every dispatch of one step from the
+        # committed PMC passes (profiles/step_traffic.py) over this run's step time
+        sj = os.path.join(ROOT, "profiles", "r2_train_c3_step_traffic.json")
+        if args.mode == "train" and args.config == "c3" and hidden == [16, 32] and gate_dtype == "bf16" \
+                and B == CONFIGS["c3"][0] and os.path.exists(sj):
+            step_bytes = json.load(open(sj)).get("hbm_bytes_per_step")
+            if step_bytes:
+                res["step_hbm"] = {"traffic_bytes_per_step": step_bytes, "source": "profiles/r2_train_c3_step_traffic.json",
+                                   "achieved": step_bytes / (dt / args.steps) / 1e9, "peak": PEAK_HBM / 1e9, "unit": "GB/s",
+                                   "frac": step_bytes / (dt / args.steps) / PEAK_HBM}
         # dominant kernel: cell-2 gate conv, one launch per timestep
         fp8 = gate_dtype == "fp8"
         tk = time_cell2_kernel_fp8(B, H, W, device) if fp8 else time_cell2_kernel(B, H, W, device)

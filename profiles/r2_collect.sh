@@ -33,6 +33,7 @@ bash profiles/prof_cfg.sh c0 train > gpurun_out/r2_prof_c0_train.txt
 bash profiles/pmc_train.sh fetch write
 python3 profiles/traffic_table.py gpurun_out/pmc_train_fetch gpurun_out/pmc_train_write gpurun_out/train_stats.csv gpurun_out/r2_train_c3_kernel_traffic.csv > gpurun_out/r2_traffic.txt
 python3 profiles/pw_traffic.py gpurun_out/pmc_train_fetch gpurun_out/pmc_train_write gpurun_out/r2_pointwise_bwd_traffic.json > /dev/null
+python3 profiles/step_traffic.py gpurun_out/pmc_train_fetch gpurun_out/pmc_train_write gpurun_out/r2_train_c3_step_traffic.json > gpurun_out/r2_step_traffic.txt
 # the fp8 cell kernel's traffic (c5 forward)
 for c in FETCH_SIZE WRITE_SIZE; do
     rm -rf gpurun_out/pmc_c5_$c && mkdir -p gpurun_out/pmc_c5_$c

@@ -10,4 +10,5 @@ cp gpurun_out/c0_train_stats.csv profiles/r2_train_c0_kernel_stats.csv
 cp gpurun_out/train_roofline_kernels_by_grid.csv profiles/r2_train_c3_roofline_kernels_by_grid.csv
 cp gpurun_out/r2_train_c3_kernel_traffic.csv profiles/r2_train_c3_kernel_traffic.csv
 cp gpurun_out/r2_pointwise_bwd_traffic.json profiles/r2_pointwise_bwd_traffic.json
+cp gpurun_out/r2_train_c3_step_traffic.json profiles/r2_train_c3_step_traffic.json
 echo copied

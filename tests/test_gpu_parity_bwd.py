@@ -190,7 +190,7 @@ def _digest_run(env_extra):
         "from pl_convlstm_gan_amd import Generator\n"
         "gpu = torch.device('cuda:0')\n"
         "for (B, T, H, W, seed, s) in [(2, 4, 37, 45, 8, 1), (3, 3, 16, 70, 11, 1), (1, 3, 64, 64, 5, 1), (4, 2, 256, 256, 3, 1),\n"
-        "                              (2, 2, 32, 32, 9, 8), (8, 2, 128, 128, 4, 1)]:\n"
+        "                              (2, 2, 32, 32, 9, 8), (8, 2, 128, 128, 4, 1), (2, 4, 256, 256, 6, 1), (1, 5, 256, 512, 7, 1)]:\n"
         "    torch.manual_seed(seed)\n"
         "    m = Generator(hidden_dims=[16, 32], lu_channels=5, scale_factor=s).to(gpu)\n"
         "    g = torch.Generator().manual_seed(seed + 1)\n"
@@ -215,12 +215,14 @@ def test_kernel_selection_switches_do_not_change_a_bit(gpu):
     recurrences, the gated post conv walking its tiles time-innermost), the
     tile-at-a-time convs, the unpaired loop, the single chains, the image-major gated conv and
     the data-gradient convs that run the pointwise backward themselves (PLC_FUSED_PW=1) must give the
-    same digest of the output and of every parameter gradient, at ragged shapes included (the last three shapes
+    same digest of the output and of every parameter gradient, at ragged shapes included (shapes four to six
     are large enough for the forward recurrence to run as two chains and for the side stream -- attention
     branches and leaf weight gradients beside the recurrences -- to be used, at scale 1 and through three
-    upsample blocks)."""
+    upsample blocks; the last two also have the four time steps from which the gate convs' weight gradients
+    are taken in two launches, the first from inside the BPTT loop, with two chains and with one)."""
     base = _digest_run({})
-    assert len(base) == 6
+    assert len(base) == 8
     for env in ({"PLC_NO_ROLLING": "1"}, {"PLC_NO_PAIRING": "1"}, {"PLC_FUSED_PW": "1"}, {"PLC_NO_BWD_SPLIT": "1"},
-                {"PLC_NO_FWD_SPLIT": "1"}, {"PLC_NO_GATED_TINNER": "1"}, {"PLC_NO_SIDE_STREAM": "1"}):
+                {"PLC_NO_FWD_SPLIT": "1"}, {"PLC_NO_GATED_TINNER": "1"}, {"PLC_NO_SIDE_STREAM": "1"},
+                {"PLC_NO_EARLY_WGRAD": "1"}):
         assert _digest_run(env) == base, env
