@@ -266,7 +266,7 @@ static int ensure_lds_limit(const void* kern, int lds, bool (&done)[64]) {
 static std::mutex plc_aux_mutex;
 struct PlcAux {
     hipStream_t stream, side;
-    hipEvent_t ev[3], sev[8];
+    hipEvent_t ev[3], sev[6];
 };
 static int plc_aux(PlcAux** out) {
     static PlcAux aux[64];
@@ -277,7 +277,7 @@ static int plc_aux(PlcAux** out) {
         PLC_HIP(hipStreamCreateWithFlags(&aux[dev].stream, hipStreamNonBlocking));
         PLC_HIP(hipStreamCreateWithFlags(&aux[dev].side, hipStreamNonBlocking));
         for (int k = 0; k < 3; ++k) PLC_HIP(hipEventCreateWithFlags(&aux[dev].ev[k], hipEventDisableTiming));
-        for (int k = 0; k < 8; ++k) PLC_HIP(hipEventCreateWithFlags(&aux[dev].sev[k], hipEventDisableTiming));
+        for (int k = 0; k < 6; ++k) PLC_HIP(hipEventCreateWithFlags(&aux[dev].sev[k], hipEventDisableTiming));
         made[dev] = true;
     }
     *out = &aux[dev];

@@ -61,31 +61,19 @@ static int arena_flush(SlabArena* ar, hipStream_t st) {
 template <int NCB0, int NCB1, int MT, int KS, int STAGE>
 static int launch_wgrad(ConvArgs in, PlcTensor dz, int mcb_valid, int n_img, SlabArena* ar,
                         float* dw, float* db, int cout, int c0, int c1, hipStream_t st,
-                        const PlcTensor* dz_mask = nullptr, int ci_off = 0, int c_total = 0, int* job = nullptr) {
+                        const PlcTensor* dz_mask = nullptr, int ci_off = 0, int c_total = 0) {
     using G = WgradGeom<NCB0 + NCB1, MT, KS>;
     if (dz_mask && STAGE == STAGE_CB8)
         return plc_fail(PLC_EUNSUPPORTED, "wgrad: the plain CB8 staging does not load a dz mask");
-    // `job` joins two launches of one conv (two ranges of its images) into one reduction: the first call
-    // (*job < 0) carves room for both launches' slabs, queues the job and returns its index; the second call
-    // puts its slabs right behind the first's.
-    const bool append = job && *job >= 0;
-    const size_t need = (job ? 2 : 1) * wgrad_slab_bytes<NCB0, NCB1, MT, KS>();
-    if (append) {
-        if (*job >= ar->tb.n || ar->tb.job[*job].dw != dw)
-            return plc_fail(PLC_EINVAL, "wgrad: the reduction job to append to is no longer pending");
-        if (ar->tb.job[*job].n_slabs > wgrad_max_blocks<NCB0, NCB1, MT, KS>())
-            return plc_fail(PLC_EINVAL, "wgrad: a reduction job takes two launches at most");
-    } else {
-        if (ar->used + need > ar->size || ar->tb.n == FINALIZE_MAX_JOBS) {
-            if (ar->no_early_flush) return plc_fail(PLC_EWORKSPACE, "wgrad: slab arena full before the streams were joined");
-            int rc = arena_flush(ar, st);
-            if (rc) return rc;
-        }
-        if (need > ar->size) return plc_fail(PLC_EWORKSPACE, "wgrad: slab arena %zu < %zu bytes", ar->size, need);
+    const size_t need = wgrad_slab_bytes<NCB0, NCB1, MT, KS>();
+    if (ar->used + need > ar->size || ar->tb.n == FINALIZE_MAX_JOBS) {
+        if (ar->no_early_flush) return plc_fail(PLC_EWORKSPACE, "wgrad: slab arena full before the streams were joined");
+        int rc = arena_flush(ar, st);
+        if (rc) return rc;
     }
-    float* slab = append ? (float*)ar->tb.job[*job].slab + (size_t)ar->tb.job[*job].n_slabs * (MT * 32) * (G::NT * 32)
-                         : (float*)(ar->base + ar->used);
-    if (!append) ar->used += need;
+    if (need > ar->size) return plc_fail(PLC_EWORKSPACE, "wgrad: slab arena %zu < %zu bytes", ar->size, need);
+    float* slab = (float*)(ar->base + ar->used);
+    ar->used += need;
     WgradArgs a;
     memset(&a, 0, sizeof(a));
     a.in = in;
@@ -118,11 +106,6 @@ static int launch_wgrad(ConvArgs in, PlcTensor dz, int mcb_valid, int n_img, Sla
     }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), G::LDS_BYTES, st, a);
     PLC_HIP(hipGetLastError());
-    if (append) {
-        ar->tb.job[*job].n_slabs += grid;
-        return PLC_OK;
-    }
-    if (job) *job = ar->tb.n;
     FinalizeJob jb;
     memset(&jb, 0, sizeof(jb));
     jb.slab = slab; jb.dw = dw; jb.db = db;
@@ -360,8 +343,7 @@ static int cell_dgrad_pw_pair(const LstmBwdArgs& pw2, const ConvArgs& c2, const 
 // h0_zero: the first n_in images of `h` are the zero initial state and are not read (a rollout
 // does not store them).
 static int cell_wgrad(const void* dz, PlcTensor x, PlcTensor h, int n_in, int n_img, SlabArena* slab,
-                      float* dw, float* db, int Cin, int Ch, int H, int W, hipStream_t st, bool h0_zero = false,
-                      int* job = nullptr) {
+                      float* dw, float* db, int Cin, int Ch, int H, int W, hipStream_t st, bool h0_zero = false) {
     const long long hw = (long long)H * W;
     ConvArgs in = conv_args(H, W, n_in);
     in.src0 = x;
@@ -369,10 +351,9 @@ static int cell_wgrad(const void* dz, PlcTensor x, PlcTensor h, int n_in, int n_
     in.zero_state = h0_zero ? 1 : 0;
     PlcTensor dzt = tens(dz, (4 * Ch / 8) * hw * 16, (long long)n_in * (4 * Ch / 8) * hw * 16);
     if (Cin == 16 && Ch == 16)
-        return launch_wgrad<2, 2, 2, 3, STAGE_CB8>(in, dzt, 8, n_img, slab, dw, db, 64, 16, 16, st, nullptr, 0, 0, job);
+        return launch_wgrad<2, 2, 2, 3, STAGE_CB8>(in, dzt, 8, n_img, slab, dw, db, 64, 16, 16, st);
     if (Cin == 16 && Ch == 32)
-        return launch_wgrad<2, 4, 4, 3, STAGE_CB8>(in, dzt, 16, n_img, slab, dw, db, 128, 16, 32, st, nullptr, 0, 0, job);
-    if (job) return plc_fail(PLC_EUNSUPPORTED, "ConvLSTM cell weight gradient in two launches: only for the widths with their own kernels");
+        return launch_wgrad<2, 4, 4, 3, STAGE_CB8>(in, dzt, 16, n_img, slab, dw, db, 128, 16, 32, st);
     if (Cin % 8 == 0 && Ch % 8 == 0)
         return wgrad_chunked<4, 4, 3, STAGE_CB8>(in, Cin, Ch, dzt, 4 * Ch, n_img, slab, dw, db, st);
     return plc_fail(PLC_EUNSUPPORTED, "ConvLSTM cell backward (Cin=%d, Ch=%d): channel counts must be multiples of 8", Cin, Ch);
@@ -556,7 +537,7 @@ static int bwd_plan(const plc_rollout_desc* d, const RolloutPlan& fp, BwdPlan* p
     p->dc1 = take((size_t)2 * B * (C1 / 8) * hw * 32);
     p->dc2 = take((size_t)2 * B * (C2 / 8) * hw * 32);
     // slab arena: the slabs of every weight-gradient launch of the pass, so one reduction at the end serves all
-    size_t sb = 2 * (wgrad_slab_bytes<2, 4, 4, 3>() + wgrad_slab_bytes<2, 2, 2, 3>());      // cell 2, cell 1 (two launches each)
+    size_t sb = wgrad_slab_bytes<2, 4, 4, 3>() + wgrad_slab_bytes<2, 2, 2, 3>();            // cell 2, cell 1
     sb += wgrad_slab_bytes<4, 0, 1, 3>() + wgrad_cout1_slab_bytes();                         // post0, post2
     sb += wgrad_slab_bytes<1, 0, 1, 3>();                                                    // stem
     sb += 2 * wgrad_slab_bytes<2, 0, 1, 1>();                                                // the two 1x1 gate convs
@@ -848,34 +829,6 @@ extern "C" int plc_generator_rollout_bwd(const plc_rollout_desc* d, const plc_ro
         return cell_dgrad_args(wb + bp.dz1 + (size_t)t * s1 * 4, wb + bp.cell1T, bpk0, wb + bp.dcat1 + (size_t)t * B * cat1,
                                B, C1, C1, H, W);
     };
-    // The gate convs' weight gradients are sums over all T*B frames and read only dz and saved activations, so
-    // each is taken in two launches: the frames of the later time steps as soon as the loop has written their dz
-    // (on the side stream, beside the rest of the loop), the earlier ones after the loop, which shortens the
-    // tail of the pass that only the weight gradients fill.  Which frames go where depends on the shape alone,
-    // and the slabs are summed in launch order, so every schedule gives the same bits.
-    const int tm = T / 2;
-    const bool wsplit = fast && T >= 4 && (long long)B * hw >= (1ll << 17);
-    int wjob2 = -1, wjob1 = -1;
-    auto cell2_wgrad_steps = [&](int t0, int t1, hipStream_t s) {      // frames of steps [t0, t1)
-        return cell_wgrad(wb + bp.dz2 + (size_t)t0 * s2 * 4, tens(wf + fp.h1s + s1 + (size_t)t0 * s1, fp.img1, (long long)B * fp.img1),
-                          tens(wf + fp.h2s + (size_t)t0 * s2, fp.img2, (long long)B * fp.img2), B, (t1 - t0) * B, slab, g->cell2_w,
-                          g->cell2_b, C1, C2, H, W, s, t0 == 0, wsplit ? &wjob2 : nullptr);
-    };
-    auto cell1_wgrad_steps = [&](int t0, int t1, hipStream_t s) {
-        return cell_wgrad(wb + bp.dz1 + (size_t)t0 * s1 * 4, tens(wf + fp.xs + (size_t)t0 * s1, fp.img1, (long long)B * fp.img1),
-                          tens(wf + fp.h1s + (size_t)t0 * s1, fp.img1, (long long)B * fp.img1), B, (t1 - t0) * B, slab, g->cell1_w,
-                          g->cell1_b, C1, C1, H, W, s, t0 == 0, wsplit ? &wjob1 : nullptr);
-    };
-    // (once pointwise pass `tm` of cell 1 has run, dz1 of steps tm.. and dz2 of steps tm-1.. are complete)
-    bool early_done = false;
-    auto early_wgrads = [&](hipStream_t s) -> int {
-        int r = cell2_wgrad_steps(tm - 1, T, s);
-        if (r) return r;
-        early_done = true;
-        return cell1_wgrad_steps(tm, T, s);
-    };
-    static const bool no_early_wgrad = [] { const char* e = getenv("PLC_NO_EARLY_WGRAD"); return e && *e && *e != '0'; }();
-    const bool early_fork = wsplit && side_aux && !no_early_wgrad;
     const bool skew = fast && T > 1 && !plc_no_rolling() && !plc_no_pairing();
     static const bool no_split = [] { const char* e = getenv("PLC_NO_BWD_SPLIT"); return e && *e && *e != '0'; }();
     // (only where a launch is long enough to pay for the second queue: on the small recurrence grids the step is
@@ -937,17 +890,9 @@ extern "C" int plc_generator_rollout_bwd(const plc_rollout_desc* d, const plc_ro
         if ((rc = run_stage(0, 0))) return rc;
         PLC_HIP(hipEventRecord(ev[1], sa));
         PLC_HIP(hipStreamWaitEvent(sb, ev[1], 0));
-        const int k_fork = 2 * (T - tm);                               // the stage with cell 1's pointwise pass of step tm
         for (int k = 1; k <= n_stage; ++k) {
             if (k < n_stage && (rc = run_stage(0, k))) return rc;
-            if (early_fork && k == k_fork) PLC_HIP(hipEventRecord(side_aux->sev[6], sa));
             if ((rc = run_stage(1, k - 1))) return rc;
-            if (early_fork && k == k_fork + 1) {
-                PLC_HIP(hipEventRecord(side_aux->sev[7], sb));
-                PLC_HIP(hipStreamWaitEvent(ss, side_aux->sev[6], 0));
-                PLC_HIP(hipStreamWaitEvent(ss, side_aux->sev[7], 0));
-                if ((rc = early_wgrads(ss))) return rc;
-            }
         }
         PLC_HIP(hipEventRecord(ev[2], sb));
         PLC_HIP(hipStreamWaitEvent(sa, ev[2], 0));
@@ -964,11 +909,6 @@ extern "C" int plc_generator_rollout_bwd(const plc_rollout_desc* d, const plc_ro
             return rc;
         for (int t = T - 1; t >= 1; --t) {
             if ((rc = lstm_pointwise_bwd_launch_pair(pw2_args(t - 1), pw1_args(t), st))) return rc;
-            if (early_fork && t == tm) {
-                PLC_HIP(hipEventRecord(side_aux->sev[6], st));
-                PLC_HIP(hipStreamWaitEvent(ss, side_aux->sev[6], 0));
-                if ((rc = early_wgrads(ss))) return rc;
-            }
             if ((rc = cell_dgrad_pair(dg2_args(t - 1), dg1_args(t), B, st))) return rc;
         }
         if ((rc = lstm_pointwise_bwd_launch(pw1_args(0), st))) return rc;
@@ -1006,14 +946,14 @@ extern "C" int plc_generator_rollout_bwd(const plc_rollout_desc* d, const plc_ro
             return rc;
     }
     // ---- gate-conv weight gradients, batched over all T*B frames -------------------------------
-    if (wsplit) {
-        if (!early_done && (rc = early_wgrads(sw))) return rc;          // no side stream: the same launches, here
-        if ((rc = cell2_wgrad_steps(0, tm - 1, st))) return rc;
-        if ((rc = cell1_wgrad_steps(0, tm, sw))) return rc;
-    } else {
-        if ((rc = cell2_wgrad_steps(0, T, st))) return rc;
-        if ((rc = cell1_wgrad_steps(0, T, sw))) return rc;
-    }
+    if ((rc = cell_wgrad(wb + bp.dz2, tens(wf + fp.h1s + s1, fp.img1, (long long)B * fp.img1),
+                         tens(wf + fp.h2s, fp.img2, (long long)B * fp.img2), B, NI, slab, g->cell2_w,
+                         g->cell2_b, C1, C2, H, W, st, true)))
+        return rc;
+    if ((rc = cell_wgrad(wb + bp.dz1, tens(wf + fp.xs, fp.img1, (long long)B * fp.img1),
+                         tens(wf + fp.h1s, fp.img1, (long long)B * fp.img1), B, NI, slab, g->cell1_w,
+                         g->cell1_b, C1, C1, H, W, sw, true)))
+        return rc;
     // ---- every conv's slabs -> parameter gradients, one launch ----------------------------------
     if (side_aux) {                      // join: every leaf has written its slabs
         PLC_HIP(hipEventRecord(side_aux->sev[5], ss));

@@ -2,7 +2,7 @@
 
   c2  128x128, T=10, B=8 on one GPU      forward + parameter gradients vs the oracle at B=2;
                                          bit-exact repeatability / batch independence at B=8
-  c3  256x256, B=2, T=4                  forward + gradients vs the oracle (weight gradients in two launches)
+  c3  256x256, B=2, T=4                  forward + gradients vs the oracle (two half-batch chains, side stream)
   c4  256x256, T=20, B=4 per GPU         full-size properties (repeatability, causality, batch
                                          independence), forward and gradients vs the oracle at B=1, T=20
   c5  512x512, T=10, B=1 per GPU         forward vs the oracle at T=2, gradients at T=2, properties at T=10
@@ -123,10 +123,8 @@ def test_c5_shape_full_horizon_properties(gpu):
     check_properties(gpu, m, *synthetic(1, 10, 512, 512, 44), t_cut=6)
 
 
-def test_c3_shape_two_launch_weight_gradients_vs_oracle(gpu):
-    """From four time steps and 2^17 pixels per step on, the gate convs' weight gradients are taken in two
-    launches per conv (later time steps from inside the BPTT loop, earlier ones after it; one slab reduction):
-    the c3 grid at B=2, T=4 takes that path with the two half-batch chains, and all gradients must still
-    match the oracle."""
+def test_c3_shape_two_chains_vs_oracle(gpu):
+    """The c3 grid at B=2, T=4: 2^17 pixels per time step, the smallest shape that runs both recurrences as
+    two half-batch chains with the leaf work on the side stream; forward and all gradients against the oracle."""
     m = model(gpu, 51)
     check_vs_oracle(gpu, m, *synthetic(2, 4, 256, 256, 52), seed=53)

@@ -218,11 +218,10 @@ def test_kernel_selection_switches_do_not_change_a_bit(gpu):
     same digest of the output and of every parameter gradient, at ragged shapes included (shapes four to six
     are large enough for the forward recurrence to run as two chains and for the side stream -- attention
     branches and leaf weight gradients beside the recurrences -- to be used, at scale 1 and through three
-    upsample blocks; the last two also have the four time steps from which the gate convs' weight gradients
-    are taken in two launches, the first from inside the BPTT loop, with two chains and with one)."""
+    upsample blocks; the last two are longer rollouts at the 2^17-pixel threshold, with two chains and, for
+    the single image, with one)."""
     base = _digest_run({})
     assert len(base) == 8
     for env in ({"PLC_NO_ROLLING": "1"}, {"PLC_NO_PAIRING": "1"}, {"PLC_FUSED_PW": "1"}, {"PLC_NO_BWD_SPLIT": "1"},
-                {"PLC_NO_FWD_SPLIT": "1"}, {"PLC_NO_GATED_TINNER": "1"}, {"PLC_NO_SIDE_STREAM": "1"},
-                {"PLC_NO_EARLY_WGRAD": "1"}):
+                {"PLC_NO_FWD_SPLIT": "1"}, {"PLC_NO_GATED_TINNER": "1"}, {"PLC_NO_SIDE_STREAM": "1"}):
         assert _digest_run(env) == base, env
