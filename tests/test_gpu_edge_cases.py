@@ -32,15 +32,19 @@ CASES = [
 ]
 
 
-def test_inference_rollout_captures_into_a_hip_graph(gpu):
+@pytest.mark.parametrize("geom", [(24, 40, 2), (256, 256, 1)])
+def test_inference_rollout_captures_into_a_hip_graph(gpu, geom):
     """The library calls are plain stream work (no allocation, no synchronisation), so a caller can
-    capture the whole inference rollout with torch.cuda.graph; the replay is bit-identical."""
+    capture the whole inference rollout with torch.cuda.graph; the replay is bit-identical.  The second
+    geometry is large enough for the rollout to fork onto the library's auxiliary streams (two half-batch
+    chains, attention branches on the side stream): the capture must follow the event forks and joins."""
     from pl_convlstm_gan_amd import Generator
+    H, W, s = geom
     torch.manual_seed(1)
-    m = Generator(hidden_dims=[16, 32], lu_channels=5, scale_factor=2).to(gpu)
-    rain = torch.rand(2, 3, 1, 24, 40, device=gpu)
-    dem = torch.rand(2, 1, 48, 80, device=gpu)
-    lu = torch.rand(2, 5, 48, 80, device=gpu)
+    m = Generator(hidden_dims=[16, 32], lu_channels=5, scale_factor=s).to(gpu)
+    rain = torch.rand(2, 3, 1, H, W, device=gpu)
+    dem = torch.rand(2, 1, H * s, W * s, device=gpu)
+    lu = torch.rand(2, 5, H * s, W * s, device=gpu)
     with torch.no_grad():
         ref = m(rain, dem, lu).clone()
     side = torch.cuda.Stream()

@@ -20,14 +20,14 @@ def _batch(seed, dev, nan=False, B=4, T=3, H=15, W=12, s=2, N=6):
     return [t.to(dev) for t in (rain, dem, lu, coords, values)]
 
 
-def _setup(gpu):
+def _setup(gpu, s=2, **geom):
     from pl_convlstm_gan_amd import Generator
     from pl_convlstm_gan_amd.losses import CombinedLoss
     from pl_convlstm_gan_amd.optim import FusedAdam
     torch.manual_seed(0)
-    model = Generator(hidden_dims=[16, 32], lu_channels=5, scale_factor=2).to(gpu)
+    model = Generator(hidden_dims=[16, 32], lu_channels=5, scale_factor=s).to(gpu)
     with torch.no_grad():
-        model(*_batch(1, gpu)[:3])           # the lazy block exists before either run starts (same RNG draw)
+        model(*_batch(1, gpu, s=s, **geom)[:3])      # the lazy block exists before either run starts (same RNG draw)
     return model, CombinedLoss(), FusedAdam(model.parameters(), lr=5e-4)
 
 
@@ -59,3 +59,29 @@ def test_graphed_step_equals_eager_step(gpu):
     assert float(opt.state_dict()["state"][0]["step"]) == float(steps_eager) == 4.0
     with pytest.raises(ValueError, match="captured for shape"):
         step(*_batch(60, gpu, B=2))
+
+
+def test_graphed_step_with_auxiliary_streams(gpu):
+    """The same at a shape (B=2, T=3, 256x256, scale 1) where both rollout calls fork onto the library's
+    auxiliary streams -- two half-batch chains in both recurrences, leaf weight gradients and the attention
+    branches on the side stream: the capture follows the event forks and joins, and the replay equals the
+    eager step bit for bit, a skipped NaN batch included."""
+    from pl_convlstm_gan_amd.training import GraphedTrainStep, train_step
+    geom = dict(B=2, T=3, H=256, W=256, s=1)
+    plan = [(11, False), (21, True), (31, False)]
+
+    model, loss_mod, opt = _setup(gpu, **geom)
+    eager = []
+    for seed, nan in plan:
+        loss, _, _, skipped = train_step(model, loss_mod, opt, *_batch(seed, gpu, nan, **geom), max_norm=0.5, nan_check="device")
+        eager.append((float(loss.detach()), bool(skipped), torch.cat([p.detach().reshape(-1) for p in model.parameters()]).clone()))
+
+    model, loss_mod, opt = _setup(gpu, **geom)
+    step = GraphedTrainStep(model, loss_mod, opt, _batch(99, gpu, **geom), max_norm=0.5)
+    for (seed, nan), (l_ref, s_ref, p_ref) in zip(plan, eager):
+        loss, _, _, skipped = step(*_batch(seed, gpu, nan, **geom))
+        got = float(loss.detach())
+        assert (got != got and l_ref != l_ref) or got == l_ref
+        assert bool(skipped) == s_ref
+        assert torch.equal(torch.cat([p.detach().reshape(-1) for p in model.parameters()]), p_ref)
+    assert [s for _, s, _ in eager] == [False, True, False]
