@@ -97,7 +97,20 @@ static int launch_wgrad(ConvArgs in, PlcTensor dz, int mcb_valid, int n_img, Sla
     a.seg_tiles = seg_tiles;
     a.n_tiles = n_img * a.in.tiles_x * cdiv(a.in.tiles_y, seg_tiles);
     a.slab = slab;
-    const int grid = a.n_tiles < max_blocks ? a.n_tiles : max_blocks;
+    int grid = a.n_tiles < max_blocks ? a.n_tiles : max_blocks;
+    if (MT == 4) {
+        // A workgroup of the 128-row kernels writes a slab of 160-230 KB, as much as four or five of its tiles
+        // read: on small grids one workgroup per tile or two made the slabs (written here, read again by the
+        // reduction) the larger part of the pass's traffic.  At least four tiles per workgroup there (x8
+        // downscaling from 32 x 32: train step -2.0 %, slab reduction 54 -> 40 us; no change from 128 x 128 up,
+        // where every workgroup has more anyway).  PLC_WGRAD_MIN_TILES=1 restores one workgroup per segment.
+        static const int min_tiles = [] { const char* e = getenv("PLC_WGRAD_MIN_TILES"); return e && *e ? atoi(e) : 4; }();
+        const long long tiles = (long long)n_img * a.in.tiles_x * a.in.tiles_y;
+        if (min_tiles > 1 && tiles / grid < min_tiles) {
+            const long long gmin = tiles / min_tiles;
+            grid = (int)(gmin < 1 ? 1 : (gmin < grid ? gmin : grid));
+        }
+    }
     auto kern = plc_wgrad_kernel<NCB0, NCB1, MT, KS, STAGE>;
     {
         static bool lds_raised[64] = {false};

@@ -59,6 +59,10 @@ extern "C" int plc_combined_loss(const plc_loss_desc* d, void* stream) {
     a.coarse_sg = (float*)((char*)d->workspace + p.off_sg);
     a.B = d->B; a.T = d->T; a.Hh = d->out_H; a.Wh = d->out_W; a.H = d->H; a.W = d->W;
     a.identity = p.n_pool == 0;
+    if (!a.identity && d->out_H % d->H == 0 && d->out_W % d->W == 0) {
+        a.sy = d->out_H / d->H;
+        a.sx = d->out_W / d->W;
+    }
     a.n_main_blocks = p.n_main; a.n_pool_blocks = p.n_pool;
     // lambda / element count of each mean, in double then rounded once
     const double bt = (double)d->B * d->T;

@@ -24,6 +24,7 @@ struct LossArgs {
     float* partials;         // [n_main_blocks][4] then [n_pool_blocks]
     int B, T, Hh, Wh, H, W;
     int identity;            // Hh == H && Wh == W
+    int sy, sx;              // Hh / H and Wh / W when both divide (every adaptive bin is an sy x sx block), else 0
     int n_main_blocks, n_pool_blocks;
     float kx, ky, kt, kc;    // lambda / element count of each mean (0 when the count is 0)
     // rain-gauge term
@@ -71,13 +72,27 @@ __global__ __launch_bounds__(256) void plc_loss_pool_kernel(const LossArgs a) {
         const long long r = idx / a.W;
         const int i = (int)(r % a.H);
         const long long bt = r / a.H;
-        const int y0 = plc_bin_lo(i, a.Hh, a.H), y1 = plc_bin_hi(i, a.Hh, a.H);
-        const int x0 = plc_bin_lo(j, a.Wh, a.W), x1 = plc_bin_hi(j, a.Wh, a.W);
         const float* p = a.pred + bt * a.Hh * a.Wh;
-        float s = 0.0f;
-        for (int y = y0; y < y1; ++y)
-            for (int x = x0; x < x1; ++x) s += p[(long long)y * a.Wh + x];
-        const float area = (float)((y1 - y0) * (x1 - x0));
+        float s = 0.0f, area;
+        if (a.sx > 0 && (a.sx & 3) == 0) {
+            // integer scale (the bins are sy x sx blocks, 16-byte aligned rows): the same sum in the same
+            // order, read as float4
+            const float* q = p + (long long)i * a.sy * a.Wh + j * a.sx;
+            for (int y = 0; y < a.sy; ++y, q += a.Wh) {
+#pragma unroll 2
+                for (int x = 0; x < a.sx; x += 4) {
+                    const float4 v = *(const float4*)(q + x);
+                    s += v.x; s += v.y; s += v.z; s += v.w;
+                }
+            }
+            area = (float)(a.sy * a.sx);
+        } else {
+            const int y0 = plc_bin_lo(i, a.Hh, a.H), y1 = plc_bin_hi(i, a.Hh, a.H);
+            const int x0 = plc_bin_lo(j, a.Wh, a.W), x1 = plc_bin_hi(j, a.Wh, a.W);
+            for (int y = y0; y < y1; ++y)
+                for (int x = x0; x < x1; ++x) s += p[(long long)y * a.Wh + x];
+            area = (float)((y1 - y0) * (x1 - x0));
+        }
         const float d = s / area - a.lr[idx];
         acc += fabsf(d);
         a.coarse_sg[idx] = plc_sgn(d) / area;
@@ -159,6 +174,11 @@ __global__ __launch_bounds__(256) void plc_loss_main_kernel(const LossArgs a) {
                 sc += fabsf(d);
                 g[k] += a.kc * plc_sgn(d);
             }
+        } else if (a.dpred && a.sx > 0) {
+            // integer scale: pixel (y, x) lies in exactly one bin, (y / sy, x / sx)
+            const float* sg = a.coarse_sg + bt * a.H * a.W + (long long)((unsigned)y / (unsigned)a.sy) * a.W;
+#pragma unroll
+            for (int k = 0; k < V; ++k) g[k] += a.kc * sg[(unsigned)(x0 + k) / (unsigned)a.sx];
         } else if (a.dpred) {
             // every adaptive bin containing (y, x): the bins of i0-1, i0, i0+1 are the only candidates
             const float* sg = a.coarse_sg + bt * a.H * a.W;
