@@ -256,6 +256,11 @@ class Generator(nn.Module):
             # training: the workspace holds the activations saved for backward and is owned by
             # the autograd node, so a second forward cannot overwrite it
             ws = ops.workspace(nbytes, device)
+        elif device.type == "cuda" and torch.cuda.is_current_stream_capturing():
+            # under stream capture the buffer comes from the graph's own memory pool and lives as long as the
+            # graph: the cached one below is dropped as soon as a call of another size comes along, and a
+            # replay would then write into memory that belongs to someone else
+            ws = ops.workspace(nbytes, device)
         else:
             key = (str(device), nbytes)
             ws = self._ws.get(key)
@@ -268,6 +273,8 @@ class Generator(nn.Module):
         return ws
 
     def _bwd_workspace(self, nbytes, device):
+        if device.type == "cuda" and torch.cuda.is_current_stream_capturing():
+            return ops.workspace(nbytes, device)       # (as in _workspace: a captured graph owns its buffers)
         key = ("bwd", str(device), nbytes)
         ws = self._ws.get(key)
         if ws is None:

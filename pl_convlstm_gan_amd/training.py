@@ -218,14 +218,25 @@ class GraphedTrainStep:
 
     * one instance serves ONE batch shape; inputs are copied into the capture's static buffers;
     * the returned tensors (loss, loss parts, prediction, skipped flag) live in the graph's memory pool
-      and are overwritten by the next replay: read or clone them before stepping again;
+      and are overwritten by the next replay: read or clone them before stepping again; they carry no
+      autograd graph;
     * the learning rate is a launch argument, so a changed ``param_groups[0]['lr']`` (ReduceLROnPlateau)
       triggers a re-capture; the Adam step count lives on the device and advances with every replay;
     * building the instance runs ``warmup`` real steps on the example batch (lazy upsample blocks,
-      workspaces, optimizer state are created outside the capture) and then restores parameters and
-      optimizer state in place, so the first replay starts from the state the caller handed in;
+      workspaces, optimizer state are created outside the capture) and then restores parameters,
+      optimizer state and the accumulated gradients of parameters the optimizer does not own, in place,
+      so the first replay starts from the state the caller handed in;
     * single process only (a captured RCCL all-reduce has not been exercised here: data-parallel
-      runs use the eager step).
+      runs use the eager step);
+    * no autograd graph of an earlier eager step over the same parameters may still be alive when the
+      instance is built (a kept ``loss`` is enough: its gradient-accumulation nodes stay bound to the stream
+      of that step and pull the legacy stream into the capture, which the HIP runtime answers with a crash
+      at the end of the capture): detach or drop such tensors first;
+    * checked for uninterrupted runs of replays and for replays after eager steps (tests/test_gpu_graph_step.py).
+      Inside host/trainer.py's epoch loop -- replays, a shorter eager batch, a download of the optimizer state
+      for the checkpoint, more replays -- later replays were observed to deviate from the eager run although
+      the same sequence outside that loop is bit-identical; the cause is not found, so the Trainer does not use
+      this class.
     """
 
     def __init__(self, model, loss_module, optimizer, example_batch, *, max_norm: float = 0.5,
@@ -242,6 +253,10 @@ class GraphedTrainStep:
             raise RuntimeError("GraphedTrainStep: the batch must be on the GPU")
         params = [p.detach().clone() for p in model.parameters()]
         had_state = optimizer.snapshot()
+        # Parameters the optimizer does not own (the reference never registers the lazily created upsample
+        # blocks) are not touched by its zero_grad(): their .grad ACCUMULATES from step to step and counts in
+        # the clip norm, exactly as in the reference.  What the warm-up adds to it must be taken back.
+        had_grad = {id(p): p.grad.detach().clone() for p in model.parameters() if p.grad is not None}
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -252,6 +267,15 @@ class GraphedTrainStep:
             for p, s in zip(model.parameters(), params):      # (the lazy blocks created by the warm-up keep their values)
                 p.copy_(s)
         optimizer.restore_(had_state)
+        owned = {id(p) for group in optimizer.param_groups for p in group["params"]}
+        with torch.no_grad():
+            for p in model.parameters():
+                if id(p) in owned or p.grad is None:
+                    continue
+                if id(p) in had_grad:
+                    p.grad.copy_(had_grad[id(p)])
+                else:
+                    p.grad.zero_()      # (accumulating into zeros gives the bits of the first assignment)
         self.graph = None
         self._capture()
 
@@ -264,9 +288,20 @@ class GraphedTrainStep:
         self.optimizer.sync_steps()
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
-            self.out = self._eager()
+            out = self._eager()
+        # Only the values leave the capture.  Its autograd graph must not: the gradient-accumulation nodes in it
+        # are bound to the capture stream, stay cached on the parameters while anything references them, and a
+        # later eager step (a shorter last batch) would then accumulate on that stream.  The buffers live in
+        # the graph's memory pool whether or not Python still references them.
+        loss, parts, pred, skipped = out
+        self.out = (loss.detach(), {k: (v.detach() if torch.is_tensor(v) else v) for k, v in parts.items()},
+                    pred.detach(), skipped)
+        del out, loss, parts, pred
         # the capture queued nothing; undo the host-side step bookkeeping it did
         self.optimizer.uncount_captured_step()
+        # whatever cached buffers of the model the captured launches point into stay alive with this object
+        # (the model drops a cached workspace as soon as a call of another size comes along)
+        self._keep = list(getattr(self.model, "_ws", {}).values()) + list(getattr(self.model, "_tabs", {}).values())
 
     def __call__(self, rain_lr, dem, lu, s_coords, s_values):
         for dst, src in zip(self.static, (rain_lr, dem, lu, s_coords, s_values)):

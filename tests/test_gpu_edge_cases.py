@@ -58,9 +58,13 @@ def test_inference_rollout_captures_into_a_hip_graph(gpu, geom):
     rain.mul_(0.5)                       # new input values in the captured buffers
     with torch.no_grad():
         ref2 = m(rain, dem, lu).clone()
+        # a call of another size drops the model's cached workspace; the graph must not have been using it
+        m(rain[:1].contiguous(), dem[:1].contiguous(), lu[:1].contiguous())
+        junk = [torch.full((1 << 20,), float("nan"), device=gpu) for _ in range(8)]      # takes over whatever was freed
     graph.replay()
     torch.cuda.synchronize()
     assert torch.equal(out, ref2) and not torch.equal(ref2, ref)
+    del junk
 
 
 @pytest.mark.parametrize("shape", [(2, 3, 16, 32, 1), (1, 2, 9, 20, 2)])

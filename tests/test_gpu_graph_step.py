@@ -20,15 +20,16 @@ def _batch(seed, dev, nan=False, B=4, T=3, H=15, W=12, s=2, N=6):
     return [t.to(dev) for t in (rain, dem, lu, coords, values)]
 
 
-def _setup(gpu, s=2, **geom):
+def _setup(gpu, s=2, lazy_block_outside_optimizer=False, **geom):
     from pl_convlstm_gan_amd import Generator
     from pl_convlstm_gan_amd.losses import CombinedLoss
     from pl_convlstm_gan_amd.optim import FusedAdam
     torch.manual_seed(0)
     model = Generator(hidden_dims=[16, 32], lu_channels=5, scale_factor=s).to(gpu)
+    opt = FusedAdam(model.parameters(), lr=5e-4) if lazy_block_outside_optimizer else None     # as the reference's Trainer does
     with torch.no_grad():
         model(*_batch(1, gpu, s=s, **geom)[:3])      # the lazy block exists before either run starts (same RNG draw)
-    return model, CombinedLoss(), FusedAdam(model.parameters(), lr=5e-4)
+    return model, CombinedLoss(), opt or FusedAdam(model.parameters(), lr=5e-4)
 
 
 def test_graphed_step_equals_eager_step(gpu):
@@ -85,3 +86,33 @@ def test_graphed_step_with_auxiliary_streams(gpu):
         assert bool(skipped) == s_ref
         assert torch.equal(torch.cat([p.detach().reshape(-1) for p in model.parameters()]), p_ref)
     assert [s for _, s, _ in eager] == [False, True, False]
+
+
+@pytest.mark.parametrize("eager_first", [0, 2])
+def test_graphed_step_with_the_lazy_block_outside_the_optimizer(gpu, eager_first):
+    """The reference builds its optimizer before the lazy upsample block exists: the block's gradients are never
+    zeroed, accumulate from step to step and count in the clip norm.  The captured step must continue that
+    accumulation exactly where the eager steps left it (or start it, when built before any step) -- the
+    warm-up's contributions taken back."""
+    from pl_convlstm_gan_amd.training import GraphedTrainStep, train_step
+    seeds = [12, 22, 32, 42, 52]
+    model, loss_mod, opt = _setup(gpu, lazy_block_outside_optimizer=True)
+    assert len(opt.param_groups[0]["params"]) == 18 and len(list(model.parameters())) == 20
+    ref = []
+    for seed in seeds:
+        train_step(model, loss_mod, opt, *_batch(seed, gpu), max_norm=0.5, nan_check="device")
+        ref.append(torch.cat([p.detach().reshape(-1) for p in model.parameters()]).clone())
+    assert not torch.equal(ref[0], ref[1])
+
+    model, loss_mod, opt = _setup(gpu, lazy_block_outside_optimizer=True)
+    got = []
+    for seed in seeds[:eager_first]:
+        out = train_step(model, loss_mod, opt, *_batch(seed, gpu), max_norm=0.5, nan_check="device")
+        got.append(torch.cat([p.detach().reshape(-1) for p in model.parameters()]).clone())
+        del out                              # no autograd graph of an eager step may outlive it
+    step = GraphedTrainStep(model, loss_mod, opt, _batch(99, gpu), max_norm=0.5)
+    for seed in seeds[eager_first:]:
+        step(*_batch(seed, gpu))
+        got.append(torch.cat([p.detach().reshape(-1) for p in model.parameters()]).clone())
+    for a, b in zip(ref, got):
+        assert torch.equal(a, b)
