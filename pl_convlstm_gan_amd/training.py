@@ -233,10 +233,12 @@ class GraphedTrainStep:
       of that step and pull the legacy stream into the capture, which the HIP runtime answers with a crash
       at the end of the capture): detach or drop such tensors first;
     * checked for uninterrupted runs of replays and for replays after eager steps (tests/test_gpu_graph_step.py).
-      Inside host/trainer.py's epoch loop -- replays, a shorter eager batch, a download of the optimizer state
-      for the checkpoint, more replays -- later replays were observed to deviate from the eager run although
-      the same sequence outside that loop is bit-identical; the cause is not found, so the Trainer does not use
-      this class.
+      KNOWN PROBLEM: when, between replays, the host both reads the prediction through indexing kernels (the
+      Trainer's station RMSE) and copies device tensors to pageable host memory (``.cpu()`` of parameters or
+      optimizer state, as a checkpoint does), a replay a few steps later computes from overwritten memory
+      (deviation, then NaN parameters); either alone is harmless.  Every buffer of this package that the
+      capture points into is alive at that time; the cause is not found (devtools/graph_replay_d2h_repro.py).
+      host/trainer.py therefore runs its steps eagerly; do not checkpoint between replays of this class.
     """
 
     def __init__(self, model, loss_module, optimizer, example_batch, *, max_norm: float = 0.5,
