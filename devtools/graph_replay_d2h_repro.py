@@ -9,7 +9,9 @@ harmless, and so are a plain synchronisation (y), device-side clones (c) and emp
 
 Every buffer the captured launches point into is alive throughout (static inputs, parameters, optimizer state,
 the lazy block's accumulated gradients, the graph's own pool), so the overwrite does not come from a freed
-tensor of this package; the cause was not found.  host/trainer.py therefore runs its steps eagerly."""
+tensor of this package; the cause was not found.  It depends on the allocation pattern: cloning the persistent
+state after every step to compare it makes the deviation disappear.  host/trainer.py therefore runs its steps
+eagerly."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
