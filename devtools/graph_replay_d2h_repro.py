@@ -13,7 +13,7 @@ tensor of this package; the cause was not found.  It depends on the allocation p
 state after every step to compare it makes the deviation disappear.  host/trainer.py therefore runs its steps
 eagerly."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from torch.utils.data import DataLoader
 from pl_convlstm_gan_amd import Generator
