@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define PLC_VERSION 100
+#define PLC_VERSION 101
 
 enum {
     PLC_OK = 0,
@@ -296,7 +296,7 @@ int plc_combined_loss(const plc_loss_desc* d, void* stream);
  * (src/training/trainer.py:311-313; Adam with the reference's settings: lr from the config, default
  * betas / eps, weight_decay = 0, no amsgrad):
  *   norm = sqrt(sum over all listed gradients of g^2);  clip = min(1, max_norm / (norm + 1e-6))
- *   g *= clip (in place, every listed tensor)
+ *   g *= clip (in place, every listed tensor; a NaN norm gives a NaN clip factor, as torch.clamp does)
  *   for tensors with update != 0:  g += weight_decay * p;  m += (1 - beta1)(g - m);
  *       v = beta2 v + (1 - beta2) g^2;  p -= lr / (1 - beta1^step) * m / (sqrt(v) / sqrt(1 - beta2^step) + eps)
  * Tensors with update == 0 count in the norm and are clipped but not stepped (the reference's
@@ -312,6 +312,7 @@ typedef struct plc_opt_tensor {
     float* exp_avg_sq;   /* Adam second moment (may be NULL when update == 0) */
     long long numel;
     int update;
+    const float* restore; /* guarded step only, may be NULL: what `grad` is set back to when the step is skipped */
 } plc_opt_tensor;
 
 size_t plc_clip_adam_workspace_bytes(const plc_opt_tensor* t, int n);
@@ -323,7 +324,13 @@ int plc_clip_adam_step(const plc_opt_tensor* t, int n, double max_norm, double l
  * `if torch.isnan(loss): continue`) decided on the device, so that the host can launch the backward
  * pass and this step without waiting for the loss:
  *   guard        device float (the loss; may be NULL = never skip).  If it is NaN the call changes
- *                nothing: parameters, moments, gradients and the counter stay as they are.
+ *                no parameter, moment or counter, and it leaves the gradients as they are except those of
+ *                table entries with a `restore` pointer: such a gradient is overwritten with the numel
+ *                floats at `restore`.  This is for tensors whose gradient ACCUMULATES over steps because no
+ *                optimizer zeroes it (the reference's optimizer is built before the generator's lazy
+ *                upsample blocks exist, trainer.py:153-158 + generator.py:129-132): the reference skips a
+ *                NaN batch BEFORE loss.backward() (trainer.py:306-310), so a caller that has already run the
+ *                backward pass hands in a copy taken before it and gets the accumulated value back.
  *   step_counter device int64, the number of updates applied so far (0 for a fresh optimizer); it is
  *                incremented by an applied update and its new value is the `step` of the formula
  *                above (bias corrections formed in double on the device).

@@ -79,7 +79,7 @@ class LossDesc(C.Structure):
 class OptTensor(C.Structure):
     """Mirror of ``plc_opt_tensor``."""
     _fields_ = [("param", _f), ("grad", _f), ("exp_avg", _f), ("exp_avg_sq", _f),
-                ("numel", C.c_longlong), ("update", C.c_int)]
+                ("numel", C.c_longlong), ("update", C.c_int), ("restore", _f)]
 
 
 _lib = None

@@ -84,6 +84,7 @@ static int clip_adam_impl(const char* who, const plc_opt_tensor* t, int n, doubl
                 const plc_opt_tensor& s = t[first + k];
                 tb.param[k] = s.param; tb.grad[k] = s.grad; tb.exp_avg[k] = s.exp_avg; tb.exp_avg_sq[k] = s.exp_avg_sq;
                 tb.update[k] = s.update;
+                tb.restore[k] = guarded ? s.restore : nullptr;
                 tb.start[k] = off;
                 off += s.numel;
             }

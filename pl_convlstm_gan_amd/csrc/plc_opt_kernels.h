@@ -19,6 +19,7 @@ struct OptTable {
     float* grad[OPT_MAX_TENSORS];
     float* exp_avg[OPT_MAX_TENSORS];
     float* exp_avg_sq[OPT_MAX_TENSORS];
+    const float* restore[OPT_MAX_TENSORS];  // guarded step: value the gradient returns to on a skip (or null)
     long long start[OPT_MAX_TENSORS + 1];   // first flat index of each tensor; start[n] = total
     int update[OPT_MAX_TENSORS];
     int n;
@@ -104,15 +105,26 @@ __global__ __launch_bounds__(256) void plc_clip_adam_kernel(const OptTable tb, c
     float s = 0.0f;
     for (int i = threadIdx.x; i < n_partials; i += 256) s += partials[i];
     const float norm = sqrtf(plc_opt_block_sum(s, red));
-    const float clip = sc.max_norm > 0.0f ? fminf(sc.max_norm / (norm + 1e-6f), 1.0f) : 1.0f;
+    // torch.clamp(max_norm / (norm + 1e-6), max=1.0): a NaN norm propagates (fminf would answer 1)
+    const float ratio = sc.max_norm / (norm + 1e-6f);
+    const float clip = sc.max_norm > 0.0f ? (ratio > 1.0f ? 1.0f : ratio) : 1.0f;
     if (grad_norm && blockIdx.x == 0 && threadIdx.x == 0) *grad_norm = norm;
+    const long long total = tb.start[tb.n];
+    const long long base = (long long)blockIdx.x * OPT_ELEMS_PER_BLOCK;
     if (dyn) {                          // guarded step: scalars and the apply/skip decision come from the device
-        if (!dyn->apply) return;        // (uniform over the launch)
+        if (!dyn->apply) {              // (uniform over the launch) skipped: only accumulated gradients go back
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const long long e = base + threadIdx.x + j * 256;
+                if (e >= total) continue;
+                const int k = plc_opt_find(tb, e);
+                if (tb.restore[k]) tb.grad[k][e - tb.start[k]] = tb.restore[k][e - tb.start[k]];
+            }
+            return;
+        }
         sc.step_size = dyn->step_size;
         sc.bc2_sqrt = dyn->bc2_sqrt;
     }
-    const long long total = tb.start[tb.n];
-    const long long base = (long long)blockIdx.x * OPT_ELEMS_PER_BLOCK;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const long long e = base + threadIdx.x + j * 256;

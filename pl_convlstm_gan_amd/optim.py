@@ -98,11 +98,12 @@ class FusedAdam(torch.optim.Optimizer):
         if not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous():
             raise RuntimeError(f"FusedAdam: {what} must be a contiguous fp32 GPU tensor (there is no CPU path)")
 
-    def _launch(self, entries, max_norm, hp, step, device, guard=None):
+    def _launch(self, entries, max_norm, hp, step, device, guard=None, restore=None):
         """entries: list of (param, update flag).  Returns the pre-clip norm (1-element tensor).
         With ``guard`` (a 1-element fp32 GPU tensor) the step is the guarded one: ``step`` is ignored,
         the device counter ``self._dev_step`` is used, and ``self.last_skipped`` (int32[1], GPU)
-        tells afterwards whether the update was skipped."""
+        tells afterwards whether the update was skipped; ``restore`` maps id(param) to the tensor its
+        gradient is set back to in that case."""
         L = _lib.lib()
         n = len(entries)
         table = (_lib.OptTensor * n)()
@@ -110,6 +111,11 @@ class FusedAdam(torch.optim.Optimizer):
             self._check(p, "grad")
             e = table[k]
             e.grad, e.numel, e.update = p.grad.data_ptr(), p.numel(), int(upd)
+            if restore and id(p) in restore:
+                r = restore[id(p)]
+                if r.shape != p.grad.shape or r.dtype != torch.float32 or not r.is_cuda or not r.is_contiguous():
+                    raise RuntimeError("FusedAdam: a restore tensor must match its gradient (contiguous fp32, GPU)")
+                e.restore = r.data_ptr()
             if upd:
                 self._check(p, "param")
                 st = self.state[p]
@@ -134,7 +140,7 @@ class FusedAdam(torch.optim.Optimizer):
 
     @torch.no_grad()
     def clip_and_step(self, clip_params: Optional[Iterable[torch.nn.Parameter]] = None, max_norm: float = 0.0,
-                      guard: Optional[torch.Tensor] = None):
+                      guard: Optional[torch.Tensor] = None, restore: Optional[dict] = None):
         """clip_grad_norm_(clip_params, max_norm) then Adam on this optimizer's parameters.
         ``clip_params`` may hold parameters the optimizer does not own (they are clipped, not
         stepped).  Returns the gradient norm before clipping as a 1-element GPU tensor, or None
@@ -144,13 +150,20 @@ class FusedAdam(torch.optim.Optimizer):
         continue`` decided on the device.  If it is NaN nothing changes (parameters, moments, step
         count); otherwise the step is the ordinary one.  No host synchronisation takes place;
         ``self.last_skipped`` (int32[1] on the GPU) holds the outcome, and the host-side ``step``
-        entries are reconciled by ``sync_steps()`` / ``state_dict()``."""
+        entries are reconciled by ``sync_steps()`` / ``state_dict()``.
+
+        ``restore`` ({id(param): tensor}, guarded steps only): gradients that a skipped step sets back to
+        the given values -- for parameters whose ``.grad`` accumulates because no optimizer zeroes it (see
+        ``training.train_step``); the gradients of all other parameters are left as the backward pass made them."""
         if guard is not None:
-            done = self._guarded(clip_params, max_norm, guard)
+            done = self._guarded(clip_params, max_norm, guard, restore)
             if done is not NotImplemented:
                 return done
             self.last_skipped = None
             if bool(torch.isnan(guard.detach()).any()):      # layouts the guarded launch does not cover: host check
+                for p in (clip_params if clip_params is not None else []):
+                    if restore and id(p) in restore and p.grad is not None:
+                        p.grad.copy_(restore[id(p)])
                 return None
         self.sync_steps()
         self._dev_step = None            # the host counters lead from here on; a guarded call re-seeds the device one
@@ -186,7 +199,7 @@ class FusedAdam(torch.optim.Optimizer):
             self._launch([(p, True) for p in ps], 0.0, group, s, device)
         return norm
 
-    def _guarded(self, clip_params, max_norm, guard):
+    def _guarded(self, clip_params, max_norm, guard, restore=None):
         """The guarded single-launch case: one parameter group, every parameter with a gradient at
         the same step count, stepped parameters inside the clip set.  NotImplemented otherwise."""
         if len(self.param_groups) != 1:
@@ -218,7 +231,10 @@ class FusedAdam(torch.optim.Optimizer):
         if g.dtype != torch.float32:
             g = g.float()
         entries = [(p, True) for p in ps] + [(p, False) for p in clip if id(p) not in stepped_ids]
-        return self._launch(entries, max_norm if clip else 0.0, group, 0, ps[0].device, guard=g.contiguous())
+        if restore and not {id(p) for p, _ in entries} >= set(restore):
+            return NotImplemented        # a tensor to put back that this launch does not list (no clipping): host path
+        return self._launch(entries, max_norm if clip else 0.0, group, 0, ps[0].device, guard=g.contiguous(),
+                            restore=restore)
 
     @torch.no_grad()
     def step(self, closure=None):

@@ -157,6 +157,38 @@ def clip_flat_(flat: torch.Tensor, max_norm: float) -> torch.Tensor:
     return norm
 
 
+def _stash_unowned_grads(optimizer, params):
+    """{id(p): copy of p.grad} for the parameters in ``params`` that ``optimizer`` does not hold (their
+    gradients accumulate over steps: optimizer.zero_grad() never sees them).  A parameter without a
+    gradient yet gets zeros and an explicit zero gradient to accumulate into, which gives the bits of the
+    first assignment.  The copies live in buffers kept on the optimizer object (same addresses every step,
+    as a captured step needs); None when every parameter is owned."""
+    owned = {id(p) for group in optimizer.param_groups for p in group["params"]}
+    loose = [p for p in params if id(p) not in owned and p.requires_grad]
+    if not loose:
+        return None
+    bufs = getattr(optimizer, "_unowned_grad_copies", None)
+    if bufs is None:
+        bufs = optimizer._unowned_grad_copies = {}
+    for k in [k for k in bufs if k not in {id(p) for p in loose}]:
+        del bufs[k]
+    src, dst = [], []
+    with torch.no_grad():
+        for p in loose:
+            b = bufs.get(id(p))
+            if b is None or b.shape != p.shape or b.device != p.device:
+                b = bufs[id(p)] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+            if p.grad is None:
+                p.grad = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                b.zero_()
+            else:
+                src.append(p.grad)
+                dst.append(b)
+        if dst:
+            torch._foreach_copy_(dst, src)
+    return bufs
+
+
 def train_step(model, loss_module, optimizer, rain_lr, dem, lu, s_coords, s_values, *, max_norm: float = 0.5,
                forward_kwargs: Optional[dict] = None, group=None, clip_params: Optional[Iterable] = None,
                nan_check: str = "sync"):
@@ -169,7 +201,14 @@ def train_step(model, loss_module, optimizer, rain_lr, dem, lu, s_coords, s_valu
       "device" (needs optim.FusedAdam) the backward pass and the optimizer step are launched at once
                and the optimizer's guarded step leaves parameters and state untouched when the loss
                (of any rank) is NaN; ``skipped`` is then a 0-dim bool GPU tensor, valid once the step
-               has run -- no host synchronisation inside the step.
+               has run -- no host synchronisation inside the step.  The reference skips a NaN batch BEFORE
+               ``loss.backward()`` (trainer.py:306-310); here the backward pass of such a batch has run by the
+               time the skip is decided, which only matters for parameters the optimizer does not own (the
+               reference builds its optimizer before the generator's lazy upsample blocks exist,
+               trainer.py:153-158): nobody zeroes their ``.grad``, it accumulates from step to step, and the
+               NaN gradients of a skipped batch would stay in it for good.  Their gradients are therefore
+               copied before the backward pass and the skipped step puts the copies back, so that after a
+               skipped batch every tensor the next step reads is what the reference would hold.
     """
     if nan_check not in ("sync", "device"):
         raise ValueError(f"nan_check must be 'sync' or 'device', not {nan_check!r}")
@@ -180,12 +219,14 @@ def train_step(model, loss_module, optimizer, rain_lr, dem, lu, s_coords, s_valu
     scale_factor = fake_hr.shape[-2] / rain_lr.shape[-2]
     loss, loss_dict = loss_module(fake_hr, rain_lr, s_coords, s_values, scale_factor)
     guard = None
+    restore = None
+    params = list(clip_params if clip_params is not None else model.parameters())
     if on_device:
         guard = loss.detach().reshape(1)
+        restore = _stash_unowned_grads(optimizer, params)
     elif any_rank_true(torch.isnan(loss.detach()), group):
         return loss, loss_dict, fake_hr, True
     loss.backward()
-    params = list(clip_params if clip_params is not None else model.parameters())
     if _dp_active(group) and fused and rain_lr.is_cuda:
         # device mode: this rank's NaN flag rides in the gradient buffer, so the step has ONE collective
         guard = exchange_grads_device(params, int(rain_lr.shape[0]), guard, group)
@@ -197,7 +238,7 @@ def train_step(model, loss_module, optimizer, rain_lr, dem, lu, s_coords, s_valu
             clip_flat_(flat[:sum(bucket.sizes)], max_norm)
         bucket.scatter()
     if fused:
-        optimizer.clip_and_step(params, max_norm, guard=guard)
+        optimizer.clip_and_step(params, max_norm, guard=guard, restore=restore)
     else:
         optimizer.step()
     if on_device:

@@ -176,3 +176,47 @@ def test_bucket_keeps_missing_gradients_missing():
     assert flat.numel() == sum(p.numel() for p in m.parameters())
     b.scatter()
     assert m.conv.weight.grad is not None and m.conv.bias.grad is None and m.gate.weight.grad is None
+
+
+def _worker_unowned(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from pl_convlstm_gan_amd.losses import CombinedLoss
+    from pl_convlstm_gan_amd.training import train_step
+    torch.manual_seed(0)
+    model = TinyRollout()
+    # the reference's arrangement: part of the model (its lazily created upsample blocks, here `gate`) is not
+    # in the optimizer, so nobody zeroes its gradient: it accumulates over the steps and counts in every clip
+    opt = torch.optim.Adam(model.conv.parameters(), lr=5e-4)
+    flags, params, loose = [], [], []
+    for k, nan_rank in enumerate((None, 1, None, None)):
+        _, _, _, s = train_step(model, CombinedLoss(), opt, *_batch(40 + 10 * k + rank, nan=(rank == nan_rank)), max_norm=0.5)
+        flags.append(s)
+        params.append([p.detach().clone() for p in model.parameters()])
+        loose.append([p.grad.detach().clone() for p in model.gate.parameters()])
+    torch.save({"flags": flags, "params": params, "loose": loose}, os.path.join(out_dir, f"rank{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_dp_nan_on_one_rank_with_parameters_outside_the_optimizer(tmp_path):
+    """good / NaN on rank 1 only / good / good, with parameters the optimizer does not own: both ranks skip the
+    second batch before its backward pass (src/training/trainer.py:306-310), so the un-zeroed gradients stay
+    finite, the skipped step changes nothing, and both ranks hold identical parameters and accumulated gradients."""
+    world = 2
+    mp.spawn(_worker_unowned, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r = [torch.load(tmp_path / f"rank{i}.pt", weights_only=True) for i in range(world)]
+    assert r[0]["flags"] == r[1]["flags"] == [False, True, False, False]
+    for step in range(4):
+        for a, b in zip(r[0]["params"][step], r[1]["params"][step]):
+            assert torch.equal(a, b) and torch.isfinite(a).all()
+        for a, b in zip(r[0]["loose"][step], r[1]["loose"][step]):
+            assert torch.equal(a, b) and torch.isfinite(a).all()
+    for a, b in zip(r[0]["params"][0], r[0]["params"][1]):
+        assert torch.equal(a, b)
+    for a, b in zip(r[0]["loose"][0], r[0]["loose"][1]):
+        assert torch.equal(a, b)                       # the skipped batch added nothing to the accumulated gradient
+    assert not torch.equal(r[0]["loose"][1][0], r[0]["loose"][2][0])
+    # the un-owned parameters never move
+    for a, b in zip(r[0]["params"][0][2:], r[0]["params"][3][2:]):
+        assert torch.equal(a, b)

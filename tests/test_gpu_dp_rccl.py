@@ -113,3 +113,31 @@ def test_pack_and_unpack_of_the_gradient_buffer(gpu):
     # a wrong buffer length is refused
     with pytest.raises(ValueError):
         _lib.check(L.plc_dp_pack_grads(ta, len(ga), fa.data_ptr(), total + 1, 3.0, None, st), "pack")
+
+
+def test_two_ranks_on_one_gpu_nan_on_one_rank(gpu):
+    """Two ranks (gloo, sharing this box's GPU) run good / NaN-on-rank-1 / good / good with the lazy upsample
+    block outside the optimizer: every rank skips the second batch, the block's accumulated gradient stays
+    finite, parameters are identical on both ranks and bit-equal to the host-checked mode
+    (tests/dp_shared_gpu_worker.py).  Ref: src/training/trainer.py:290-315."""
+    import subprocess
+    import sys
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "dp_shared_gpu_worker.py")
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, "-u", worker], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = []
+    try:
+        for p in procs:
+            outs.append(p.communicate(timeout=150)[0])
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    for rank, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, f"rank {rank}:\n{o[-3000:]}"

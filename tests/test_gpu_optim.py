@@ -200,3 +200,73 @@ def test_train_step_device_nan_check_equals_sync(gpu):
         assert torch.isfinite(b).all() and torch.equal(a, b)
     opt.sync_steps()
     assert {float(s["step"]) for s in opt.state.values()} == {2.0}
+
+
+def _lazy_block_run(gpu, mode, plan):
+    """A generator at scale 2 with the optimizer built BEFORE the first forward, as the reference's Trainer
+    does (src/training/trainer.py:153-158): the lazily created upsample block is outside the optimizer, nobody
+    zeroes its gradient, it accumulates and counts in every clip norm."""
+    from pl_convlstm_gan_amd import Generator
+    from pl_convlstm_gan_amd.losses import CombinedLoss
+    from pl_convlstm_gan_amd.optim import FusedAdam
+    from pl_convlstm_gan_amd.training import train_step
+    torch.manual_seed(21)
+    m = Generator(hidden_dims=[16, 32], lu_channels=5, scale_factor=2).to(gpu)
+    opt = FusedAdam(m.parameters(), lr=5e-4)
+    assert m.upsample_blocks is None
+    g = torch.Generator().manual_seed(22)
+    flags, lazy_grads = [], []
+    for bad in plan:
+        rain = (10 * torch.rand(2, 3, 1, 12, 20, generator=g)).to(gpu)
+        dem = torch.rand(2, 1, 24, 40, generator=g).to(gpu)
+        lu = torch.rand(2, 5, 24, 40, generator=g).to(gpu)
+        coords = torch.randint(0, 12, (6, 2), generator=g).to(gpu)
+        values = (20 * torch.rand(2, 3, 6, generator=g)).to(gpu)
+        if bad:
+            values = values - 100.0          # log1p(< -1) -> NaN loss, and NaN gradients from its backward pass
+        _, _, _, skipped = train_step(m, CombinedLoss(), opt, rain, dem, lu, coords, values, max_norm=0.5, nan_check=mode)
+        flags.append(bool(skipped))
+        lazy_grads.append([None if p.grad is None else p.grad.detach().clone() for p in m.upsample_blocks.parameters()])
+    torch.cuda.synchronize()
+    owned = {id(p) for grp in opt.param_groups for p in grp["params"]}
+    assert all(id(p) not in owned for p in m.upsample_blocks.parameters())
+    return [p.detach().clone() for p in m.parameters()], flags, lazy_grads
+
+
+@pytest.mark.parametrize("plan", [[False, True, False, False], [True, False, True, False]])
+def test_device_nan_skip_with_the_lazy_block_outside_the_optimizer(gpu, plan):
+    """The reference leaves a NaN batch BEFORE loss.backward() (trainer.py:306-310).  With the skip decided on
+    the device the backward pass of that batch has run; its NaN gradients must not stay in the accumulating
+    gradient of the block nobody zeroes, or every later clip norm is NaN.  Parameters after good / NaN / good /
+    good batches are bit-equal to the host-checked mode, and so is the block's accumulated gradient."""
+    p_sync, f_sync, g_sync = _lazy_block_run(gpu, "sync", plan)
+    p_dev, f_dev, g_dev = _lazy_block_run(gpu, "device", plan)
+    assert f_sync == plan == f_dev
+    for a, b in zip(p_sync, p_dev):
+        assert torch.isfinite(b).all() and torch.equal(a, b)
+    for step, (gs, gd) in enumerate(zip(g_sync, g_dev)):
+        for a, b in zip(gs, gd):
+            if a is None:               # (NaN batch first: the host-checked mode has made no gradient yet)
+                assert b is None or not b.any()
+            else:
+                assert torch.isfinite(b).all() and torch.equal(a, b), step
+
+
+def test_non_finite_clip_norm_propagates_like_clip_grad_norm(gpu):
+    """torch.nn.utils.clip_grad_norm_ multiplies by clamp(max_norm / (norm + 1e-6), max=1): a NaN norm gives a
+    NaN factor and NaN gradients (and parameters after the step).  The fused step does the same instead of
+    silently switching the clip off."""
+    from pl_convlstm_gan_amd.optim import FusedAdam
+    mine, ref = _make(gpu, 7), _make(gpu, 7)
+    opt_m, opt_r = FusedAdam(mine, lr=5e-4), torch.optim.Adam(ref, lr=5e-4)
+    for p, q, g in zip(mine, ref, _grads(0, 1.0)):
+        p.grad, q.grad = g.clone().to(gpu), g.clone().to(gpu)
+    mine[2].grad.view(-1)[5] = float("nan")
+    ref[2].grad.view(-1)[5] = float("nan")
+    torch.nn.utils.clip_grad_norm_(ref, 0.5)
+    opt_r.step()
+    norm = opt_m.clip_and_step(mine, 0.5)
+    assert torch.isnan(norm).all()
+    for p, q in zip(mine, ref):
+        assert torch.isnan(q.grad).all() and torch.isnan(p.grad).all()
+        assert torch.isnan(q).all() and torch.isnan(p).all()
