@@ -552,7 +552,8 @@ static int launch_persistent_th(PersistArgs p, int n_img, int T, hipStream_t st,
     // resident for the barrier to complete, and a second process (or stream) doing the same on this GPU
     // must still find room for ITS whole grid.  Larger grids have launches long enough not to need this.
     if (per_cu <= 0 || grid > per_cu * cu_count() / 4) return PLC_OK;
-    PLC_HIP(hipMemsetAsync(p.c1.sync, 0, sizeof(unsigned), st));
+    hipLaunchKernelGGL(plc_zero_words_kernel, dim3(1), dim3(64), 0, st, (unsigned*)p.c1.sync, 1);
+    PLC_HIP(hipGetLastError());
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, p);
     PLC_HIP(hipGetLastError());
     *done = true;

@@ -619,7 +619,9 @@ extern "C" int plc_generator_rollout_bwd(const plc_rollout_desc* d, const plc_ro
     const int mcb = cdiv(C2 / 2, 8);
     const long long fimg = (C2 / 8) * ohw * 16;   // one C2-channel image at output resolution
 
-    PLC_HIP(hipMemsetAsync(wb + bp.bpk0, 0, bwd_zero_bias_floats(C1, C2) * sizeof(float), st));
+    hipLaunchKernelGGL(plc_zero_words_kernel, dim3(1), dim3(256), 0, st, (unsigned*)(wb + bp.bpk0),
+                       (int)bwd_zero_bias_floats(C1, C2));
+    PLC_HIP(hipGetLastError());
     const bool fast = widths_fast(C1, C2);
     const int gen = fast ? 0 : 1;
     // ---- transposed (data-gradient) weights -------------------------------------------------

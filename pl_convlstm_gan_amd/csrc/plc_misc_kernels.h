@@ -122,6 +122,13 @@ __global__ void plc_pack_multi_kernel(const PackTable tb) {
     plc_pack_weight_body(tb.job[j], blockIdx.x - tb.job[j].first_block, tb.job[j].n_blocks);
 }
 
+// Zero n 32-bit words.  Used in place of hipMemsetAsync: inside a captured HIP graph a memset node of this
+// runtime is not reliably ordered between the kernel nodes around it (devtools/graph_memset_probe.hip), a
+// kernel node is.
+__global__ void plc_zero_words_kernel(unsigned* __restrict__ p, int n) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = 0u;
+}
+
 // NCHW fp32 -> CB8 bf16 (channels padded with zeros to a multiple of 8).
 __global__ void plc_nchw_to_cb8_kernel(const float* __restrict__ src, uint4* __restrict__ dst,
                                        int N, int C, int H, int W) {

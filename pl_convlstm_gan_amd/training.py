@@ -248,6 +248,25 @@ def train_step(model, loss_module, optimizer, rain_lr, dem, lu, s_coords, s_valu
     return loss, loss_dict, fake_hr, False
 
 
+def params_in_a_live_autograd_graph(params) -> list:
+    """The parameters among ``params`` whose gradient-accumulation node is kept alive by somebody else, i.e. that
+    an existing autograd graph (a loss or an output that has not been detached or dropped) still points at.
+    A parameter's accumulation node is cached on the parameter only weakly: it dies with the last graph that
+    uses it, and a new one is made on the next use.  So a mark left in the node's metadata is found again only
+    if some graph held the node in between."""
+    def node(p):
+        return p.expand_as(p).grad_fn.next_functions[0][0]
+
+    params = [p for p in params if p.requires_grad]
+    mark = object()
+    for p in params:
+        node(p).metadata["plc_live_probe"] = mark
+    held = [p for p in params if node(p).metadata.get("plc_live_probe") is mark]
+    for p in held:
+        node(p).metadata.pop("plc_live_probe", None)
+    return held
+
+
 class GraphedTrainStep:
     """``train_step(..., nan_check="device")`` captured once into a HIP graph and replayed.
 
@@ -270,16 +289,21 @@ class GraphedTrainStep:
     * single process only (a captured RCCL all-reduce has not been exercised here: data-parallel
       runs use the eager step);
     * no autograd graph of an earlier eager step over the same parameters may still be alive when the
-      instance is built (a kept ``loss`` is enough: its gradient-accumulation nodes stay bound to the stream
-      of that step and pull the legacy stream into the capture, which the HIP runtime answers with a crash
-      at the end of the capture): detach or drop such tensors first;
-    * checked for uninterrupted runs of replays and for replays after eager steps (tests/test_gpu_graph_step.py).
-      KNOWN PROBLEM: when, between replays, the host both reads the prediction through indexing kernels (the
-      Trainer's station RMSE) and copies device tensors to pageable host memory (``.cpu()`` of parameters or
-      optimizer state, as a checkpoint does), a replay a few steps later computes from overwritten memory
-      (deviation, then NaN parameters); either alone is harmless.  Every buffer of this package that the
-      capture points into is alive at that time; the cause is not found (devtools/graph_replay_d2h_repro.py).
-      host/trainer.py therefore runs its steps eagerly; do not checkpoint between replays of this class.
+      instance is built (a kept ``loss`` is enough: its gradient-accumulation nodes stay bound to the stream of
+      that step and pull the legacy stream into the capture, which the HIP runtime answers with a crash at the
+      end of the capture).  The constructor checks for it and raises a RuntimeError that says so: detach or drop
+      such tensors first;
+    * checked against the eager step bit for bit: uninterrupted runs of replays, replays after eager steps, and
+      replays between which the host reads the prediction through indexing kernels and copies parameters and
+      optimizer state to the host, as a Trainer with a station RMSE and a checkpoint does
+      (tests/test_gpu_graph_step.py).  The library issues no ``hipMemsetAsync``: with its two memset nodes in the
+      captured step (the zero bias rows of the data-gradient convs, the persistent kernel's barrier counter) some
+      replays computed from memory the node should have cleared, and which replay did depended on what the host
+      did in between.  On fixed inputs the first wrong tensor was the output of the first data-gradient conv
+      (some channels NaN: its bias rows are that memset's target) while prediction, loss and the gradient formed
+      before that conv were right.  Small kernels do the clearing now (plc_zero_words_kernel); a memset node
+      alone between two kernels of a minimal graph stays ordered (devtools/graph_memset_probe.hip), so what the
+      runtime does with it inside the larger captured step was not established.
     """
 
     def __init__(self, model, loss_module, optimizer, example_batch, *, max_norm: float = 0.5,
@@ -288,6 +312,12 @@ class GraphedTrainStep:
             raise TypeError("GraphedTrainStep needs optim.FusedAdam (the NaN-batch skip must run on the device)")
         if _world() > 1:
             raise RuntimeError("GraphedTrainStep is single-process: use train_step under data parallelism")
+        held = params_in_a_live_autograd_graph(model.parameters())
+        if held:
+            raise RuntimeError(
+                f"GraphedTrainStep: an autograd graph of an earlier step still references {len(held)} parameter(s) of the "
+                "model (a kept loss or prediction that was not detached): its gradient-accumulation nodes are bound to "
+                "that step's stream and would pull it into the capture.  Detach or delete those tensors first.")
         self.model, self.loss_module, self.optimizer = model, loss_module, optimizer
         self.max_norm, self.forward_kwargs = max_norm, forward_kwargs
         self.clip_params = list(clip_params) if clip_params is not None else None

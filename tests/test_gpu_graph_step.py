@@ -116,3 +116,95 @@ def test_graphed_step_with_the_lazy_block_outside_the_optimizer(gpu, eager_first
         got.append(torch.cat([p.detach().reshape(-1) for p in model.parameters()]).clone())
     for a, b in zip(ref, got):
         assert torch.equal(a, b)
+
+
+def test_replays_with_index_reads_and_host_copies_between_them(gpu):
+    """What a Trainer does between steps -- reads the prediction at the rain gauges through indexing kernels, and
+    once per epoch copies parameters and optimizer state to the host (a checkpoint) -- with the lazy block outside
+    the optimizer, on the reference's 15x12 basin grid (the single-launch persistent recurrence): 14 replays equal
+    14 eager steps bit for bit.  (With hipMemsetAsync nodes in the captured step this sequence ended in NaN
+    parameters; the library clears with kernels now.)"""
+    from pl_convlstm_gan_amd.training import GraphedTrainStep, train_step
+    geom = dict(B=48, T=5, H=15, W=12, s=2, N=10)
+
+    def run(graph):
+        model, loss_mod, opt = _setup(gpu, lazy_block_outside_optimizer=True, **geom)
+        step, losses, kept = None, [], None
+        for k in range(14):
+            b = _batch(100 + k, gpu, **geom)
+            if graph and k > 0:
+                if step is None:
+                    step = GraphedTrainStep(model, loss_mod, opt, b, max_norm=0.5)
+                loss, parts, fake, skipped = step(*b)
+            else:
+                loss, parts, fake, skipped = train_step(model, loss_mod, opt, *b, max_norm=0.5, nan_check="device")
+            loss, fake = loss.detach(), fake.detach()
+            assert not bool(skipped)
+            losses.append(loss.item())
+            coords = b[3][0]
+            hr = ((coords.float() + 0.5) * 2.0 - 0.5).long()
+            rows, cols = hr[:, 0], hr[:, 1]
+            inside = (rows >= 0) & (rows < fake.shape[-2]) & (cols >= 0) & (cols < fake.shape[-1])
+            at = fake[:, :, 0][:, :, rows[inside], cols[inside]]
+            truth = b[4][:, :, inside]
+            seen = ~torch.isnan(truth)
+            rmse = torch.sqrt(((at[seen] - truth[seen]) ** 2).mean()).item()
+            kept = (at, truth, inside, rmse)                     # alive across the next step, as the Trainer keeps them
+            if k % 7 == 6:
+                sd = opt.state_dict()
+                host = [v.cpu() for st in sd["state"].values() for v in st.values() if torch.is_tensor(v)]
+                host += [p.detach().cpu() for p in model.parameters()]
+        return losses, torch.cat([p.detach().reshape(-1) for p in model.parameters()]).clone()
+
+    l_eager, p_eager = run(False)
+    l_graph, p_graph = run(True)
+    assert l_eager == l_graph
+    assert torch.isfinite(p_graph).all() and torch.equal(p_eager, p_graph)
+
+
+def test_many_replays_of_forward_loss_backward_on_fixed_inputs(gpu):
+    """Forward + CombinedLoss + backward captured once and replayed 80 times on fixed inputs and parameters:
+    prediction, loss and every parameter gradient of every replay equal the eager pass bit for bit."""
+    from pl_convlstm_gan_amd.losses import CombinedLoss
+    geom = dict(B=48, T=5, H=15, W=12, s=2, N=10)
+    model, loss_mod, _ = _setup(gpu, **geom)
+    rain, dem, lu, coords, values = _batch(7, gpu, **geom)
+
+    def one():
+        for p in model.parameters():
+            p.grad = None
+        out = model(rain, dem, lu)
+        loss, _ = loss_mod(out, rain, coords, values, 2.0)
+        loss.backward()
+        return out.detach(), loss.detach()
+
+    def snap(out, loss):
+        return [p.grad.clone() for p in model.parameters()] + [out.clone(), loss.clone()]
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            o, l = one()
+    torch.cuda.current_stream().wait_stream(side)
+    ref = snap(o, l)
+    del o, l
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        o, l = one()
+    for rep in range(80):
+        graph.replay()
+        for k, (a, b) in enumerate(zip(ref, snap(o, l))):
+            assert torch.equal(a, b), (rep, k)
+
+
+def test_building_beside_a_live_autograd_graph_is_refused(gpu):
+    """A loss kept from an eager step keeps that step's gradient-accumulation nodes (and their stream) alive;
+    capturing then used to end in a crash inside the HIP runtime.  The constructor says what is wrong instead."""
+    from pl_convlstm_gan_amd.training import GraphedTrainStep, train_step
+    model, loss_mod, opt = _setup(gpu)
+    kept = train_step(model, loss_mod, opt, *_batch(10, gpu), max_norm=0.5, nan_check="device")
+    with pytest.raises(RuntimeError, match="autograd graph of an earlier step"):
+        GraphedTrainStep(model, loss_mod, opt, _batch(99, gpu), max_norm=0.5)
+    del kept
+    GraphedTrainStep(model, loss_mod, opt, _batch(99, gpu), max_norm=0.5)(*_batch(11, gpu))

@@ -145,3 +145,29 @@ def test_built_library_has_no_packed_fp32_with_a_selected_second_source(tmp_path
     assert not bad, bad[:5]
     # what remains is the hand-written plain form of the one-channel weight gradient
     assert all("op_sel" not in ln for ln in packed), [ln.strip() for ln in packed if "op_sel" in ln][:5]
+
+
+def test_live_autograd_graph_detection():
+    """training.params_in_a_live_autograd_graph: what GraphedTrainStep refuses to be built beside."""
+    import torch
+    from pl_convlstm_gan_amd.training import params_in_a_live_autograd_graph as held
+    ps = [torch.nn.Parameter(torch.randn(3)), torch.nn.Parameter(torch.randn(2)), torch.nn.Parameter(torch.randn(2), requires_grad=False)]
+    assert held(ps) == []
+    loss = (ps[0] * 2).sum()
+    assert [id(p) for p in held(ps)] == [id(ps[0])]
+    loss.backward()
+    assert [id(p) for p in held(ps)] == [id(ps[0])]          # a kept loss keeps the nodes, graph buffers freed or not
+    detached = loss.detach()
+    del loss
+    assert held(ps) == [] and held(ps) == []
+
+
+def test_the_library_issues_no_memset():
+    """A hipMemsetAsync inside a captured training step gave wrong replays on this runtime (see
+    training.GraphedTrainStep); the library clears memory with kernels and must not import the call."""
+    import shutil
+    import subprocess
+    from pl_convlstm_gan_amd import _lib
+    nm = shutil.which("nm") or "/opt/rocm/lib/llvm/bin/llvm-nm"
+    syms = subprocess.run([nm, "-D", "--undefined-only", _lib.LIB_PATH], check=True, capture_output=True, text=True).stdout
+    assert "hipMemset" not in syms, [l for l in syms.splitlines() if "hipMemset" in l]
