@@ -17,9 +17,12 @@
  *     part of their work on the auxiliary streams (independent halves of the batch, work that nothing
  *     in the recurrence waits for): it is forked from `stream` by an event and joined back into it
  *     before the call's last launch, so for the caller everything is ordered on `stream` as if it
- *     had run there, and a stream capture of the call is valid.  Rollout calls on one device share the
+ *     had run there, and a stream capture of the call is valid; a call that fails after such a fork still
+ *     joins the auxiliary streams before it returns its error code.  Rollout calls on one device share the
  *     auxiliary streams: calls issued from several host threads at once are serialised there (their
- *     results are unaffected);
+ *     results are unaffected).  A stream capture that contains a rollout call pulls the auxiliary streams
+ *     into the capture until it ends: while such a capture is open, no other thread may issue rollout
+ *     calls on that device (they would be enqueued onto a capturing stream);
  *   - tensors crossing the boundary are fp32, NCHW-contiguous, 16-byte aligned, exactly as the
  *     reference's modules take and return them.  Internally activations are kept as bf16 in a
  *     channel-blocked layout ("CB8": [image][C/8][H][W][8]) with fp32 accumulation and an fp32

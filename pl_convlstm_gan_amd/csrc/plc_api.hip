@@ -284,6 +284,41 @@ static int plc_aux(PlcAux** out) {
     return PLC_OK;
 }
 
+// Joins, on every way out of a rollout call, the auxiliary streams the call has forked onto.  A fork is an event
+// recorded on the caller's stream and awaited by the auxiliary one; if the call then fails half way (a launch
+// error, a full slab arena) and simply returned, work on the auxiliary stream would still be reading and
+// writing the caller's workspace after the caller has been told the call is over, and under stream capture
+// the capture would end with un-joined work.  opened() notes a fork and the event of its join, joined() that
+// the regular join has been issued; the destructor issues the join of whatever is still open.
+struct ForkGuard {
+    hipStream_t main;
+    hipStream_t forked[2];
+    hipEvent_t join_ev[2];
+    int n;
+    explicit ForkGuard(hipStream_t m) : main(m), n(0) {}
+    void opened(hipStream_t s, hipEvent_t join) {
+        for (int k = 0; k < n; ++k) if (forked[k] == s) return;
+        if (n < 2) { forked[n] = s; join_ev[n] = join; ++n; }
+    }
+    void joined(hipStream_t s) {
+        for (int k = 0; k < n; ++k)
+            if (forked[k] == s) { forked[k] = forked[n - 1]; join_ev[k] = join_ev[n - 1]; --n; return; }
+    }
+    ~ForkGuard() {
+        for (int k = 0; k < n; ++k)
+            if (hipEventRecord(join_ev[k], forked[k]) == hipSuccess) (void)hipStreamWaitEvent(main, join_ev[k], 0);
+    }
+    ForkGuard(const ForkGuard&) = delete;
+    ForkGuard& operator=(const ForkGuard&) = delete;
+};
+
+// Test hook: PLC_DEBUG_FAIL_AFTER_FORK=1 in the environment makes the rollout calls fail right after they have
+// forked onto an auxiliary stream, which is the only way to reach ForkGuard's destructor path on purpose.
+static bool plc_debug_fail_after_fork() {
+    static const bool on = [] { const char* e = getenv("PLC_DEBUG_FAIL_AFTER_FORK"); return e && *e && *e != '0'; }();
+    return on;
+}
+
 // One instantiation at a fixed tile height TH (and K split).
 template <int NCB0, int NCB1, int NMT, int KS, int STAGE, int EPI, int TH, int KSPLIT = 1>
 static int launch_conv_th(ConvArgs a, int n_img, int n_mgroups, hipStream_t st) {
@@ -546,8 +581,14 @@ static int launch_persistent_th(PersistArgs p, int n_img, int T, hipStream_t st,
     }
     p.n1 = p.c1.n_blocks;
     const int grid = p.c1.n_blocks + p.c2.n_blocks;
-    int per_cu = 0;
-    PLC_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)kern, 256, lds));
+    // (resident workgroups per CU of this instantiation: an immutable fact, asked once per device)
+    static int per_cu_cached[64] = {0};
+    const int dev = current_device();
+    int per_cu = dev >= 0 ? per_cu_cached[dev] : 0;
+    if (per_cu == 0) {
+        PLC_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)kern, 256, lds));
+        if (dev >= 0 && per_cu > 0) per_cu_cached[dev] = per_cu;
+    }
     // Only grids that take at most a quarter of the chip's workgroup slots: the whole grid must be
     // resident for the barrier to complete, and a second process (or stream) doing the same on this GPU
     // must still find room for ITS whole grid.  Larger grids have launches long enough not to need this.
@@ -972,6 +1013,7 @@ extern "C" int plc_generator_rollout_fwd(const plc_rollout_desc* d, void* stream
         return plc_fail(PLC_EWORKSPACE, "rollout: workspace %zu < %zu bytes", d->workspace_bytes, p.total);
 
     hipStream_t st = (hipStream_t)stream;
+    ForkGuard forks(st);         // joins the auxiliary streams on an early (error) return too
     char* ws = (char*)d->workspace;
     const int B = d->B, T = d->T, H = d->H, W = d->W, C1 = d->C1, C2 = d->C2, L = d->L;
     const int oH = d->out_H, oW = d->out_W;
@@ -1009,6 +1051,7 @@ extern "C" int plc_generator_rollout_fwd(const plc_rollout_desc* d, void* stream
         if ((rc = plc_aux(&side_aux))) return rc;
         PLC_HIP(hipEventRecord(side_aux->sev[0], (hipStream_t)stream));          // the packed weights are ready
         PLC_HIP(hipStreamWaitEvent(side_aux->side, side_aux->sev[0], 0));
+        forks.opened(side_aux->side, side_aux->sev[1]);
     }
     {
         hipStream_t st = side_aux ? side_aux->side : (hipStream_t)stream;        // (this block's stream)
@@ -1188,7 +1231,9 @@ extern "C" int plc_generator_rollout_fwd(const plc_rollout_desc* d, void* stream
             };
             PLC_HIP(hipEventRecord(aux->ev[0], st));
             PLC_HIP(hipStreamWaitEvent(aux->stream, aux->ev[0], 0));
+            forks.opened(aux->stream, aux->ev[2]);
             if ((rc = stage(0, 0))) return rc;
+            if (plc_debug_fail_after_fork()) return plc_fail(PLC_EHIP, "rollout: injected failure after the stream fork");
             PLC_HIP(hipEventRecord(aux->ev[1], st));
             PLC_HIP(hipStreamWaitEvent(aux->stream, aux->ev[1], 0));
             for (int k = 1; k <= T + 1; ++k) {
@@ -1197,6 +1242,7 @@ extern "C" int plc_generator_rollout_fwd(const plc_rollout_desc* d, void* stream
             }
             PLC_HIP(hipEventRecord(aux->ev[2], aux->stream));
             PLC_HIP(hipStreamWaitEvent(st, aux->ev[2], 0));
+            forks.joined(aux->stream);
         } else if (!persistent && fast && T > 1 && !plc_no_pairing()) {
             // cell 1 (0) | cell 2 (t-1) + cell 1 (t), t = 1 .. T-1 | cell 2 (T-1)
             if ((rc = launch_cell(cell1(0), B, C1, C1, st))) return rc;
@@ -1245,7 +1291,10 @@ extern "C" int plc_generator_rollout_fwd(const plc_rollout_desc* d, void* stream
         PLC_HIP(hipGetLastError());
         feat = ws + p.fin;
     }
-    if (side_aux) PLC_HIP(hipStreamWaitEvent(st, side_aux->sev[1], 0));           // the gate maps are ready
+    if (side_aux) {
+        PLC_HIP(hipStreamWaitEvent(st, side_aux->sev[1], 0));           // the gate maps are ready
+        forks.joined(side_aux->side);
+    }
     {
         ConvArgs a = conv_args(oH, oW, B);
         a.src0 = tens(feat, (C2 / 8) * ohw * 16, (long long)B * (C2 / 8) * ohw * 16);

@@ -232,7 +232,8 @@ static LstmBwdArgs lstm_pointwise_bwd_args(Cb8View dh0, Cb8View dh1, Cb8View dh2
     LstmBwdArgs a;
     a.B = B; a.ncb = Ch / 8; a.H = H; a.W = W;
     // (PLC_DC_FP32 in the environment keeps the rollout's dc in fp32: A/B timing and accuracy checks)
-    a.dc_bf16 = dc_bf16 && !getenv("PLC_DC_FP32");
+    static const bool dc_fp32 = [] { const char* e = getenv("PLC_DC_FP32"); return e && *e && *e != '0'; }();
+    a.dc_bf16 = dc_bf16 && !dc_fp32;
     a.dh0 = dh0; a.dh1 = dh1; a.dh2 = dh2;
     a.dh0_mul = dh0_mul;
     a.dc_in = (const char*)dc_in; a.gates = (const char*)gates;
@@ -597,6 +598,7 @@ extern "C" int plc_generator_rollout_bwd(const plc_rollout_desc* d, const plc_ro
         return plc_fail(PLC_EWORKSPACE, "rollout backward: forward workspace %zu < %zu bytes", d->workspace_bytes, fp.total);
 
     hipStream_t st = (hipStream_t)stream;
+    ForkGuard forks(st);              // joins the auxiliary streams on an early (error) return too
     char* wf = (char*)d->workspace;   // forward workspace: saved activations
     char* wb = (char*)g->workspace;   // backward scratch
     const int B = d->B, T = d->T, H = d->H, W = d->W, C1 = d->C1, C2 = d->C2, L = d->L, NI = B * T;
@@ -644,6 +646,7 @@ extern "C" int plc_generator_rollout_bwd(const plc_rollout_desc* d, const plc_ro
     if (side_aux) {
         PLC_HIP(hipEventRecord(side_aux->sev[4], st));
         PLC_HIP(hipStreamWaitEvent(ss, side_aux->sev[4], 0));
+        forks.opened(ss, side_aux->sev[5]);
     }
 
     // ---- output convs -------------------------------------------------------------------------
@@ -882,6 +885,7 @@ extern "C" int plc_generator_rollout_bwd(const plc_rollout_desc* d, const plc_ro
         hipStream_t sh[2] = {sa, sb};
         PLC_HIP(hipEventRecord(ev[0], sa));
         PLC_HIP(hipStreamWaitEvent(sb, ev[0], 0));
+        forks.opened(sb, ev[2]);
         // stage k of a chain: 0 = pw2(T-1), 1 = dg2(T-1), then for t = T-1..1: pair pw, pair dg; then pw1(0), dg1(0)
         const int n_stage = 2 + 2 * (T - 1) + 2;
         auto run_stage = [&](int h, int k) -> int {
@@ -903,6 +907,7 @@ extern "C" int plc_generator_rollout_bwd(const plc_rollout_desc* d, const plc_ro
         };
         // chain B starts one stage behind chain A
         if ((rc = run_stage(0, 0))) return rc;
+        if (plc_debug_fail_after_fork()) return plc_fail(PLC_EHIP, "rollout backward: injected failure after the stream fork");
         PLC_HIP(hipEventRecord(ev[1], sa));
         PLC_HIP(hipStreamWaitEvent(sb, ev[1], 0));
         for (int k = 1; k <= n_stage; ++k) {
@@ -911,6 +916,7 @@ extern "C" int plc_generator_rollout_bwd(const plc_rollout_desc* d, const plc_ro
         }
         PLC_HIP(hipEventRecord(ev[2], sb));
         PLC_HIP(hipStreamWaitEvent(sa, ev[2], 0));
+        forks.joined(sb);
     } else if (skew && plc_fused_pw()) {
         // T + 1 launches: each conv forms its own input (the pointwise pass runs inside it)
         if ((rc = cell_dgrad_pw<16, 2, 2>(pw2_args(T - 1), dg2_args(T - 1), B, st))) return rc;
@@ -973,6 +979,7 @@ extern "C" int plc_generator_rollout_bwd(const plc_rollout_desc* d, const plc_ro
     if (side_aux) {                      // join: every leaf has written its slabs
         PLC_HIP(hipEventRecord(side_aux->sev[5], ss));
         PLC_HIP(hipStreamWaitEvent(st, side_aux->sev[5], 0));
+        forks.joined(ss);
     }
     return arena_flush(&arena, st);
 }

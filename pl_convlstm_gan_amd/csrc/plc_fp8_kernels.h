@@ -89,7 +89,7 @@ __global__ __launch_bounds__(1024) void plc_pack_lstm_fp8_kernel(const PackFp8Jo
         e = e > 100 ? 100 : (e < -100 ? -100 : e);
         e_sh = e;
         if (part == 0) {
-            jb.scale_word[0] = 0x01010101 * (127 - e);
+            jb.scale_word[0] = (int)(0x01010101u * (unsigned)(127 - e));   // the E8M0 byte in all four lanes' positions (unsigned: no overflow)
             jb.scale_word[1] = e;
         }
     }

@@ -228,3 +228,79 @@ def test_rollouts_from_two_host_threads(gpu):
     for k in range(2):
         for out in results[k]:
             assert torch.equal(out, jobs[k][4])
+
+
+def test_a_call_that_fails_after_forking_still_joins_its_streams(gpu):
+    """Both rollout calls put part of their work on auxiliary streams of the library.  A call that fails after
+    such a fork must join them before it returns (else a stream capture ends with un-joined work, and eagerly
+    the auxiliary stream is still using the caller's workspace after the error).  PLC_DEBUG_FAIL_AFTER_FORK=1
+    injects the failure; run in a fresh process because the library reads the switch once."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, torch\n"
+        f"sys.path.insert(0, {root!r})\n"
+        "from pl_convlstm_gan_amd import Generator\n"
+        "gpu = torch.device('cuda:0')\n"
+        "torch.manual_seed(0)\n"
+        "m = Generator(hidden_dims=[16, 32], lu_channels=5, scale_factor=1).to(gpu)\n"
+        "g = torch.Generator().manual_seed(1)\n"
+        "B, T, H, W = 2, 3, 256, 256          # large enough for the two half-batch chains\n"
+        "rain, dem, lu = (torch.rand(B, T, 1, H, W, generator=g).to(gpu), torch.rand(B, 1, H, W, generator=g).to(gpu),\n"
+        "                 torch.rand(B, 5, H, W, generator=g).to(gpu))\n"
+        "def attempt():\n"
+        "    try:\n"
+        "        with torch.no_grad():\n"
+        "            m(rain, dem, lu)\n"
+        "    except RuntimeError as e:\n"
+        "        assert 'injected failure' in str(e), e\n"
+        "        return True\n"
+        "    return False\n"
+        "assert attempt()\n"
+        "torch.cuda.synchronize()\n"
+        "side = torch.cuda.Stream()\n"
+        "side.wait_stream(torch.cuda.current_stream())\n"
+        "graph = torch.cuda.CUDAGraph()\n"
+        "with torch.cuda.graph(graph):          # ends with an error if anything forked is left un-joined\n"
+        "    assert attempt()\n"
+        "graph.replay()\n"
+        "torch.cuda.synchronize()\n"
+        "print('joined')\n")
+    env = dict(os.environ, PLC_DEBUG_FAIL_AFTER_FORK="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=150)
+    assert r.returncode == 0 and "joined" in r.stdout, (r.stdout[-1000:], r.stderr[-3000:])
+
+
+def test_long_rollout_gradients_with_open_forget_gates(gpu):
+    """The backward pass carries dL/dc from step to step as bf16.  That running sum passes through the product
+    of the forget gates of all later steps, so its rounding compounds with T: checked here against autograd
+    of the oracle at T = 32 with the forget-gate biases raised to +3 (f ~ 0.95: the cell state's gradient
+    survives the whole rollout), to the bounds of the short-rollout parity tests (3e-2 max and L2)."""
+    from pl_convlstm_gan_amd import Generator
+    B, T, H, W = 1, 32, 24, 40
+    torch.manual_seed(31)
+    m = Generator(hidden_dims=[16, 32], lu_channels=5, scale_factor=1)
+    with torch.no_grad():
+        for cell, ch in ((m.cell1, 16), (m.cell2, 32)):
+            cell.conv.bias[ch:2 * ch] += 3.0            # gate order i, f, o, g
+    gen = torch.Generator().manual_seed(32)
+    rain = 10 * torch.rand(B, T, 1, H, W, generator=gen) * (torch.rand(B, T, 1, H, W, generator=gen) > 0.5)
+    dem = torch.rand(B, 1, H, W, generator=gen)
+    lu = torch.rand(B, 5, H, W, generator=gen)
+    # only the LAST frames carry gradient, so every parameter gradient reaches the early steps through the recurrence
+    wgt = torch.zeros(B, T, 1, H, W)
+    wgt[:, -2:] = torch.rand(B, 2, 1, H, W, generator=gen) + 0.5
+    m = m.to(gpu)
+    out = m(rain.to(gpu), dem.to(gpu), lu.to(gpu))
+    (out * wgt.to(gpu)).sum().backward()
+    params = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    leaf = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    emu = O.generator_forward(leaf, rain, dem, lu, scale_factor=1, emulate="bf16")
+    assert float((out.detach().cpu() - emu.detach()).abs().max()) <= 4e-3 * float(emu.detach().abs().max())
+    (emu * wgt).sum().backward()
+    worst = {k: (relmax(p.grad.cpu(), leaf[k].grad), rel_l2(p.grad.cpu(), leaf[k].grad)) for k, p in m.named_parameters()}
+    print({k: (round(a, 4), round(b, 4)) for k, (a, b) in worst.items()})
+    for k, (emax, el2) in worst.items():
+        assert emax <= 3e-2 and el2 <= 3e-2, (k, emax, el2)

@@ -36,14 +36,33 @@ def test_noalloc_cell_matches_the_workspace_entry_point(gpu):
                                            h_ref.data_ptr(), c_ref.data_ptr(), ws.data_ptr(), need,
                                            B, Cin, Ch, H, W, st), "plc_convlstm_cell_fwd")
         h_out, c_out = torch.full_like(h, float("nan")), torch.full_like(c, float("nan"))
+
+        def call():
+            _lib.check(L.plc_convlstm_cell_fwd_noalloc(x.data_ptr(), h.data_ptr(), c.data_ptr(), w.data_ptr(), b.data_ptr(),
+                                                       h_out.data_ptr(), c_out.data_ptr(), B, Cin, Ch, H, W, ops._stream()),
+                       "plc_convlstm_cell_fwd_noalloc")
+        # one unmeasured call per shape class: the first use on a device looks the array's address up and raises
+        # the kernels' LDS limits (one-time host work that the documentation asks callers to do before a capture)
+        call()
         torch.cuda.synchronize()
-        before = torch.cuda.memory_allocated()
-        _lib.check(L.plc_convlstm_cell_fwd_noalloc(x.data_ptr(), h.data_ptr(), c.data_ptr(), w.data_ptr(), b.data_ptr(),
-                                                   h_out.data_ptr(), c_out.data_ptr(), B, Cin, Ch, H, W, st),
-                   "plc_convlstm_cell_fwd_noalloc")
+        # memory_allocated() only sees PyTorch's caching allocator; mem_get_info() is the driver's free memory
+        # and would also show a hipMalloc made inside the library
+        before, free_before = torch.cuda.memory_allocated(), torch.cuda.mem_get_info()[0]
+        h_out.fill_(float("nan"))
+        c_out.fill_(float("nan"))
+        call()
         torch.cuda.synchronize()
-        assert torch.cuda.memory_allocated() == before
+        assert torch.cuda.memory_allocated() == before and torch.cuda.mem_get_info()[0] == free_before
         assert torch.isfinite(h_out).all() and torch.isfinite(c_out).all()
+        assert torch.equal(h_out, h_ref) and torch.equal(c_out, c_ref)
+        # and under stream capture, where any allocating or synchronising HIP call inside the library is an error
+        h_out.fill_(float("nan"))
+        c_out.fill_(float("nan"))
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+            call()
+        graph.replay()
+        torch.cuda.synchronize()
         assert torch.equal(h_out, h_ref) and torch.equal(c_out, c_ref)
 
 
