@@ -2,7 +2,7 @@
 """Benchmark of the ConvLSTM rollout hot path on MI355X.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--mode train|fwd] [--config c3|c2|c1|c4|c5|p2|c0]
-                    [--global-batch G]
+                    [--global-batch G | --shard]
 
 With --gpus N > 1 and no torchrun environment the script starts the N ranks itself (one process per
 GPU, `python -m torch.distributed.run --nproc-per-node N`) before anything touches a GPU, and fails
@@ -14,9 +14,11 @@ One "step" = one pass of the hot path over one batch of synthetic, HBM-resident 
                    -> gradient all-reduce (N > 1) -> clip_grad_norm(0.5) -> Adam step
                    (the reference's step, src/training/trainer.py:290-315)
   fwd:             the rollout forward under no_grad (inference)
-The default workload is the per-GPU shard of BASELINE.json configs[2] (256x256 frames, T=10,
-global batch 32 on 8 GPUs = 4 per GPU, scale_factor=1): the batch is sharded over ranks, the
-only collective is the gradient all-reduce, per-GPU work is fixed (weak scaling).
+The default workload is BASELINE.json configs[2], the configuration the metric is quoted on: 256x256
+frames, T=10, GLOBAL batch 32, scale_factor=1.  The batch is sharded over the ranks (32 / N per GPU: the
+whole batch on one GPU at N=1, the 4-per-GPU shard at N=8), the only collective is the gradient
+all-reduce, total work is fixed (strong scaling).  --shard runs the configuration's per-GPU shard of its
+own GPU count on every rank instead (c3: B=4 per GPU whatever N is; weak scaling).
 Rank 0 prints ONE JSON line.
 """
 import argparse
@@ -35,14 +37,14 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 CONFIGS = {
-    # name: (B per GPU, T, H, W, scale)   -- H, W are the LR grid; output is (H*scale, W*scale)
-    "c1": (2, 10, 64, 64, 1),      # BASELINE configs[0] shape (CPU plumbing case)
-    "c2": (8, 10, 128, 128, 1),    # configs[1]
-    "c3": (4, 10, 256, 256, 1),    # configs[2] per-GPU shard (the shape the metric is quoted on)
-    "c4": (4, 20, 256, 256, 1),    # configs[3] per-GPU shard (generator only)
-    "c5": (1, 10, 512, 512, 1),    # configs[4] per-GPU shard; its gate convs default to the fp8 (e4m3) path
-    "p2": (4, 10, 32, 32, 8),      # default.yaml-faithful x8 downscaling to 256x256
-    "c0": (8, 5, 15, 12, 8),       # the reference's own shape: default.yaml (batch 8, T=5, x8) on its 15x12 basin grid -> 120x96
+    # name: (global batch, GPUs the configuration names, T, H, W, scale)   -- H, W are the LR grid; output is (H*scale, W*scale)
+    "c1": (2, 1, 10, 64, 64, 1),      # BASELINE configs[0] shape (CPU plumbing case)
+    "c2": (8, 1, 10, 128, 128, 1),    # configs[1]
+    "c3": (32, 8, 10, 256, 256, 1),   # configs[2]: the configuration the metric is quoted on (4 per GPU on its 8 GPUs)
+    "c4": (16, 4, 20, 256, 256, 1),   # configs[3] (generator only; 4 per GPU on its 4 GPUs)
+    "c5": (8, 8, 10, 512, 512, 1),    # configs[4] (1 per GPU on its 8 GPUs); its gate convs default to the fp8 (e4m3) path
+    "p2": (32, 8, 10, 32, 32, 8),     # default.yaml-faithful x8 downscaling to 256x256, c3's batch
+    "c0": (8, 1, 5, 15, 12, 8),       # the reference's own shape: default.yaml (batch 8, T=5, x8) on its 15x12 basin grid -> 120x96
 }
 FLOP_PER_PX_FWD = 171104          # algorithmic forward FLOPs per output pixel per frame (scale 1, L=5)
 FWD_BYTES_PER_PX = 804            # algorithmic forward tensor traffic per pixel per frame: 402 elements as bf16
@@ -143,30 +145,38 @@ def time_cell2_kernel_fp8(B, H, W, device, iters=50):
     return e0.elapsed_time(e1) * 1e-3 / iters
 
 
-def time_pointwise_bwd_kernel(B, H, W, device, Ch=32, iters=50):
-    """Average duration of the kernel that takes the largest share of a train step (the pointwise
-    LSTM backward, here at cell 2's width with two incoming dh and dc', as in every step but the
-    last), measured with events on the stream it is launched on."""
+def time_pointwise_bwd_launch(B, H, W, device, iters=50):
+    """Average duration of the launch that takes the largest share of a train step, as the step issues it:
+    the pointwise LSTM backward of cell 2 (step t - 1) and of cell 1 (step t) in ONE launch
+    (plc_lstm_pointwise_bwd_pair_kernel), each with two incoming dh and dc' as in every step of the loop
+    but its ends, over B images (the step runs it on each half of its batch).  Measured with events on the
+    stream it is launched on."""
     from pl_convlstm_gan_amd import _lib, ops
     L = _lib.lib()
-    ncb = Ch // 8
     bf = lambda *shape: (torch.randn(*shape, device=device) * 0.5).to(torch.bfloat16).view(torch.int16)
-    # four operand sets used in rotation (> 1 GB in total), so that no launch finds its inputs in the
+    # operand sets used in rotation (> 1 GB in total), so that no launch finds its inputs in the
     # 256 MB Infinity Cache: in the step the gates and cell states were written long before
+    per_set = B * 6 * H * W * (3 * 16 + 64 + 32 + 64 + 16)
     sets = []
-    for _ in range(4):
-        gates = torch.rand(B, 4 * ncb, H, W, 8, device=device).to(torch.bfloat16).view(torch.int16)
-        c_prev = torch.randn(B, ncb, H, W, 8, device=device)
-        sets.append((bf(B, ncb, H, W, 8), bf(B, ncb, H, W, 8), bf(B, ncb, H, W, 8), gates,
-                     c_prev, torch.empty_like(gates), bf(B, ncb, H, W, 8)))
-    img = ncb * H * W * 16
+    for _ in range(max(2, min(6, (1 << 30) // per_set + 1))):
+        cells = []
+        for Ch in (32, 16):
+            ncb = Ch // 8
+            gates = torch.rand(B, 4 * ncb, H, W, 8, device=device).to(torch.bfloat16).view(torch.int16)
+            c_prev = torch.randn(B, ncb, H, W, 8, device=device)
+            t = (bf(B, ncb, H, W, 8), bf(B, ncb, H, W, 8), bf(B, ncb, H, W, 8), gates, c_prev, torch.empty_like(gates),
+                 bf(B, ncb, H, W, 8))
+            a = _lib.PointwiseBwdArgs()
+            a.dh0, a.dh1, a.dc_next, a.gates, a.c_prev, a.dz, a.dc = (x.data_ptr() for x in t)
+            a.dh0_image_bytes = a.dh1_image_bytes = ncb * H * W * 16
+            a.Ch = Ch
+            cells.append((a, t))
+        sets.append(cells)
     st = ops._stream()
 
     def run(k):
-        dh0, dh1, dc_in, gates, c_prev, dz, dc = sets[k % len(sets)]
-        _lib.check(L.plc_lstm_pointwise_bwd_bf16dc(dh0.data_ptr(), img, dh1.data_ptr(), img, None, 0, dc_in.data_ptr(),
-                                            gates.data_ptr(), c_prev.data_ptr(), dz.data_ptr(), dc.data_ptr(),
-                                            B, Ch, H, W, st), "pointwise_bwd")
+        (a2, _), (a1, _) = sets[k % len(sets)]
+        _lib.check(L.plc_lstm_pointwise_bwd_pair_bf16dc(a2, a1, B, H, W, st), "pointwise_bwd_pair")
     for k in range(5):
         run(k)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -207,6 +217,14 @@ def cpu_baseline(mode, B, T, H, W, s, params):
             "sample": f"B={Bc} of the per-GPU workload (T={T}, {H * s}x{W * s}), fp32 PyTorch-CPU oracle {what}, best of 3"}
 
 
+def first_existing(*names):
+    """The first of profiles/<name> that exists (this round's record before an older one), else the first name."""
+    for n in names:
+        if os.path.exists(os.path.join(ROOT, "profiles", n)):
+            return os.path.join(ROOT, "profiles", n)
+    return os.path.join(ROOT, "profiles", names[0])
+
+
 def launch_ranks(n, argv):
     """Start n ranks of this script under torch.distributed.run (a child process; nothing here has
     touched a GPU yet) and return its exit code."""
@@ -226,8 +244,11 @@ def main():
     ap.add_argument("--mode", default="train", choices=["train", "fwd"])
     ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
     ap.add_argument("--global-batch", type=int, default=0,
-                    help="total batch over all ranks (strong-scaling anchor, e.g. 32 for BASELINE configs[2]); "
-                         "default: the config's per-GPU batch on every rank (weak scaling)")
+                    help="total batch over all ranks (default: the configuration's own global batch, 32 for "
+                         "BASELINE configs[2]; strong scaling)")
+    ap.add_argument("--shard", action="store_true",
+                    help="every rank runs the configuration's per-GPU shard of its own GPU count (c3: B=4 per GPU) "
+                         "whatever --gpus is: weak scaling")
     ap.add_argument("--hidden", default="16,32", help="hidden_dims of the generator (the benchmark configs use 16,32; "
                     "32,64 is the reference's class default and runs on the run-time-width kernels)")
     ap.add_argument("--gate-dtype", default=None, choices=["bf16", "fp8"],
@@ -282,15 +303,20 @@ def main():
     from pl_convlstm_gan_amd.losses import CombinedLoss
     from pl_convlstm_gan_amd.training import train_step
 
-    B, T, H, W, s = CONFIGS[args.config]
+    GB, native_gpus, T, H, W, s = CONFIGS[args.config]
+    if args.shard and args.global_batch:
+        raise SystemExit("bench.py: --shard and --global-batch exclude each other")
     if args.shape:
         B, T, H, W, s = (int(v) for v in args.shape.split(","))
         args.config = "custom"
-    scaling = "weak"
-    if args.global_batch:
-        if args.global_batch % world:
-            raise SystemExit(f"bench.py: --global-batch {args.global_batch} does not divide over {world} ranks")
-        B, scaling = args.global_batch // world, "strong"
+        scaling = "weak"                      # (the given B on every rank)
+    elif args.shard:
+        B, scaling = GB // native_gpus, "weak"
+    else:
+        GB = args.global_batch or GB
+        if GB % world:
+            raise SystemExit(f"bench.py: the global batch {GB} does not divide over {world} ranks")
+        B, scaling = GB // world, "strong"
     torch.manual_seed(0)                       # identical initial weights on every rank
     hidden = [int(v) for v in args.hidden.split(",")]
     model = Generator(hidden_dims=hidden, lu_channels=5, scale_factor=s)
@@ -382,22 +408,27 @@ def main():
             res["fwd_hbm_frac"] = FWD_BYTES_PER_PX * px * world * B * T / (dt_fwd / n_fwd) / (world * PEAK_HBM)
         # the train step against the HBM roof by MEASURED traffic: bytes of every dispatch of one step from the
         # committed PMC passes (profiles/step_traffic.py) over this run's step time
-        sj = os.path.join(ROOT, "profiles", "r2_train_c3_step_traffic.json")
+        sj = first_existing("r3_train_c3_step_traffic.json") if B == 32 else \
+            first_existing("r3_train_c3_shard_step_traffic.json", "r2_train_c3_step_traffic.json")
         if args.mode == "train" and args.config == "c3" and hidden == [16, 32] and gate_dtype == "bf16" \
-                and B == CONFIGS["c3"][0] and os.path.exists(sj):
+                and B in (4, 32) and os.path.exists(sj):
             step_bytes = json.load(open(sj)).get("hbm_bytes_per_step")
             if step_bytes:
-                res["step_hbm"] = {"traffic_bytes_per_step": step_bytes, "source": "profiles/r2_train_c3_step_traffic.json",
+                res["step_hbm"] = {"traffic_bytes_per_step": step_bytes, "source": os.path.relpath(sj, ROOT),
                                    "achieved": step_bytes / (dt / args.steps) / 1e9, "peak": PEAK_HBM / 1e9, "unit": "GB/s",
                                    "frac": step_bytes / (dt / args.steps) / PEAK_HBM}
         # dominant kernel: cell-2 gate conv, one launch per timestep
         fp8 = gate_dtype == "fp8"
-        tk = time_cell2_kernel_fp8(B, H, W, device) if fp8 else time_cell2_kernel(B, H, W, device)
-        flops = CELL2_FLOP_PER_PX * B * H * W
+        # (a forward recurrence that runs as two half-batch chains launches the cell on half the batch)
+        Bk = B // 2 if (not fp8 and B >= 2 and B * H * W >= (1 << 17)) else B
+        tk = time_cell2_kernel_fp8(Bk, H, W, device) if fp8 else time_cell2_kernel(Bk, H, W, device)
+        flops = CELL2_FLOP_PER_PX * Bk * H * W
         traffic = None
-        tj = os.path.join(ROOT, "profiles", "r1_cell2_traffic.json")
+        tj = first_existing("r3_cell2_traffic.json", "r1_cell2_traffic.json")
         if os.path.exists(tj) and args.config == "c3":
-            traffic = json.load(open(tj)).get("hbm_bytes_per_launch")
+            rec = json.load(open(tj))
+            if rec.get("images_per_launch", 4) == Bk:                       # (a record of the launch size timed here)
+                traffic = rec.get("hbm_bytes_per_launch")
         peak = PEAK_FP8 if fp8 else PEAK_BF16
         fp8_traffic = None
         fj = os.path.join(ROOT, "profiles", "r2_cell2_fp8_traffic.json")
@@ -411,18 +442,26 @@ def main():
                      "achieved": flops / tk / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s",
                      "frac": flops / tk / peak, "traffic": fp8_traffic if fp8 else traffic,
                      "launch_us": tk * 1e6, "flop_per_launch": flops,
-                     "alg_bytes_per_launch": cell_bytes * B * H * W,
-                     "hbm_frac": cell_bytes * B * H * W / tk / PEAK_HBM}
+                     "images_per_launch": Bk,
+                     "alg_bytes_per_launch": cell_bytes * Bk * H * W,
+                     "hbm_frac": cell_bytes * Bk * H * W / tk / PEAK_HBM}
         if args.mode == "train":
             # the kernel with the largest share of a train step is the HBM-bound pointwise LSTM
             # backward (2T launches); the cell-2 conv, top kernel of the forward, follows as roofline_mfma
-            tp = time_pointwise_bwd_kernel(B, H, W, device)
-            pw_bytes = PW_BWD_BYTES_PER_UNIT * B * 4 * H * W          # cell 2: 4 channel blocks per pixel
+            # the launch as the step issues it: both cells' passes in one launch, on each half of the batch when the
+            # backward recurrence runs as two chains (B >= 2 and at least 2^17 pixels per time step)
+            nb = B // 2 if (B >= 2 and B * H * W >= (1 << 17)) else B
+            tp = time_pointwise_bwd_launch(nb, H, W, device)
+            pw_bytes = PW_BWD_BYTES_PER_UNIT * nb * 6 * H * W         # cell 2: 4 channel blocks per pixel, cell 1: 2
             pw_traffic = None
-            pj = os.path.join(ROOT, "profiles", "r2_pointwise_bwd_traffic.json")
+            pj = first_existing("r3_pointwise_bwd_pair_traffic.json")
             if os.path.exists(pj) and args.config == "c3":
-                pw_traffic = json.load(open(pj)).get("hbm_bytes_per_launch")
-            res["roofline"] = {"bound": "hbm", "kernel": "plc_lstm_pointwise_bwd_kernel (cell 2, one timestep)",
+                rec = json.load(open(pj))
+                if rec.get("images_per_launch") == nb:
+                    pw_traffic = rec.get("hbm_bytes_per_launch")
+            res["roofline"] = {"bound": "hbm",
+                               "kernel": f"plc_lstm_pointwise_bwd_pair_kernel (cell 2 of step t-1 + cell 1 of step t, {nb} images: "
+                                         "the launch of the skewed BPTT loop" + (", one of its two half-batch chains)" if nb != B else ")"),
                                "achieved": pw_bytes / tp / 1e9, "peak": PEAK_HBM / 1e9, "unit": "GB/s",
                                "frac": pw_bytes / tp / PEAK_HBM, "traffic": pw_traffic,
                                "launch_us": tp * 1e6, "alg_bytes_per_launch": pw_bytes}

@@ -238,6 +238,24 @@ int plc_lstm_pointwise_bwd_bf16dc(const void* dh0, long long dh0_image_bytes, co
                                   const void* dh2, long long dh2_image_bytes, const void* dc_next, const void* gates,
                                   const float* c_prev, void* dz, void* dc, int B, int Ch, int H, int W, void* stream);
 
+/* Two such passes in ONE launch: what the rollout's backward pass issues per step of its skewed loop (cell 2 of
+ * step t - 1 and cell 1 of step t wait for the same data-gradient conv and for nothing else, so they share a
+ * launch; plc_generator_rollout_bwd runs it on each half of the batch).  Every field as the argument of the same
+ * name of plc_lstm_pointwise_bwd_bf16dc; B, H, W are common to both.  Exported so that the benchmark can time the
+ * launch the training step really makes. */
+typedef struct plc_pointwise_bwd_args {
+    const void* dh0; long long dh0_image_bytes;
+    const void* dh1; long long dh1_image_bytes;
+    const void* dc_next;     /* CB8 bf16 or NULL */
+    const void* gates;
+    const float* c_prev;     /* CB8 fp32 or NULL */
+    void* dz;
+    void* dc;                /* CB8 bf16 */
+    int Ch;
+} plc_pointwise_bwd_args;
+int plc_lstm_pointwise_bwd_pair_bf16dc(const plc_pointwise_bwd_args* first, const plc_pointwise_bwd_args* second,
+                                       int B, int H, int W, void* stream);
+
 typedef struct plc_rollout_grads {
     const float* grad_out;   /* dL/d out, fp32 [B][T][1][out_H][out_W] */
     /* parameter gradients (fp32, device, same shapes as the parameters; overwritten) */

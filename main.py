@@ -3,6 +3,7 @@
 Under ``python -m torch.distributed.run --nproc-per-node N main.py ...`` it trains data-parallel
 (one process per GPU, RCCL gradient all-reduce)."""
 import argparse
+import datetime
 import os
 
 import torch
@@ -17,7 +18,11 @@ def main():
         import torch.distributed as dist
         local = int(os.environ.get("LOCAL_RANK", "0"))
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        # a collective that does not complete aborts the ranks instead of hanging (PLC_PG_TIMEOUT seconds, default 600)
+        patience = datetime.timedelta(seconds=int(os.environ.get("PLC_PG_TIMEOUT", "600")))
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local), timeout=patience)
     from src.training.trainer import Trainer
     trainer = Trainer(config_name=args.config)
     trainer.config.validate()

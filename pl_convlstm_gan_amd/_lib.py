@@ -21,6 +21,7 @@ EXPORTS = (
     "plc_fp8_packed_weight_bytes", "plc_pack_lstm_weight_fp8", "plc_cb8_bf16_to_cb16_fp8", "plc_convlstm_cell_fwd_fp8",
     "plc_generator_workspace_bytes", "plc_generator_rollout_fwd", "plc_generator_workspace_offset",
     "plc_convlstm_cell_bwd_workspace_bytes", "plc_convlstm_cell_bwd", "plc_lstm_pointwise_bwd", "plc_lstm_pointwise_bwd_bf16dc",
+    "plc_lstm_pointwise_bwd_pair_bf16dc",
     "plc_generator_bwd_workspace_bytes", "plc_generator_rollout_bwd",
     "plc_combined_loss_workspace_bytes", "plc_combined_loss",
     "plc_clip_adam_workspace_bytes", "plc_clip_adam_step", "plc_clip_adam_step_guarded",
@@ -82,6 +83,12 @@ class OptTensor(C.Structure):
                 ("numel", C.c_longlong), ("update", C.c_int), ("restore", _f)]
 
 
+class PointwiseBwdArgs(C.Structure):
+    """Mirror of ``plc_pointwise_bwd_args``."""
+    _fields_ = [("dh0", _f), ("dh0_image_bytes", C.c_longlong), ("dh1", _f), ("dh1_image_bytes", C.c_longlong),
+                ("dc_next", _f), ("gates", _f), ("c_prev", _f), ("dz", _f), ("dc", _f), ("Ch", C.c_int)]
+
+
 _lib = None
 
 
@@ -141,6 +148,8 @@ def lib():
     L.plc_lstm_pointwise_bwd.argtypes = [p, C.c_longlong, p, C.c_longlong, p, C.c_longlong, p, p, p, p, p, i, i, i, i, p]
     L.plc_lstm_pointwise_bwd_bf16dc.restype = i
     L.plc_lstm_pointwise_bwd_bf16dc.argtypes = [p, C.c_longlong, p, C.c_longlong, p, C.c_longlong, p, p, p, p, p, i, i, i, i, p]
+    L.plc_lstm_pointwise_bwd_pair_bf16dc.restype = i
+    L.plc_lstm_pointwise_bwd_pair_bf16dc.argtypes = [C.POINTER(PointwiseBwdArgs), C.POINTER(PointwiseBwdArgs), i, i, i, p]
     L.plc_generator_bwd_workspace_bytes.restype = sz
     L.plc_generator_bwd_workspace_bytes.argtypes = [C.POINTER(RolloutDesc)]
     L.plc_generator_rollout_bwd.restype = i

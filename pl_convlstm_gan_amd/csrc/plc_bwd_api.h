@@ -426,6 +426,23 @@ extern "C" int plc_lstm_pointwise_bwd_bf16dc(const void* dh0, long long dh0_imag
                               Cb8View{nullptr, 0}, 1);
 }
 
+extern "C" int plc_lstm_pointwise_bwd_pair_bf16dc(const plc_pointwise_bwd_args* first, const plc_pointwise_bwd_args* second,
+                                                  int B, int H, int W, void* stream) {
+    PLC_REQUIRE(first && second, "plc_lstm_pointwise_bwd_pair_bf16dc: null argument block");
+    PLC_REQUIRE(B > 0 && H > 0 && W > 0, "plc_lstm_pointwise_bwd_pair_bf16dc: non-positive size");
+    LstmBwdArgs a[2];
+    const plc_pointwise_bwd_args* in[2] = {first, second};
+    for (int k = 0; k < 2; ++k) {
+        const plc_pointwise_bwd_args& q = *in[k];
+        PLC_REQUIRE(q.gates && q.dz && q.dc, "plc_lstm_pointwise_bwd_pair_bf16dc: null pointer");
+        PLC_REQUIRE(q.Ch > 0 && q.Ch % 8 == 0, "plc_lstm_pointwise_bwd_pair_bf16dc: Ch must be a positive multiple of 8");
+        a[k] = lstm_pointwise_bwd_args(view(q.dh0, q.dh0_image_bytes), view(q.dh1, q.dh1_image_bytes), view(nullptr, 0),
+                                       q.dc_next, q.gates, q.c_prev, nullptr, q.dz, q.dc, B, q.Ch, H, W,
+                                       Cb8View{nullptr, 0}, 1);
+    }
+    return lstm_pointwise_bwd_launch_pair(a[0], a[1], (hipStream_t)stream);
+}
+
 extern "C" size_t plc_convlstm_cell_bwd_workspace_bytes(int B, int Cin, int Ch, int H, int W) {
     if (B <= 0 || Cin <= 0 || Ch <= 0 || H <= 0 || W <= 0) return 0;
     return cell_bwd_ws(B, Cin, Ch, H, W).total;

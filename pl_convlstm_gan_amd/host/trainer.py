@@ -3,9 +3,9 @@
 Same constructor, attributes (config, device, output_dir, history, best_rmse, best_epoch,
 early_stopping, model, optimizer, scheduler, loss_module, train_loader / val_loader / test_loader /
 dataloader) and methods (setup_data, setup_model, validate, compute_station_rmse, train_epoch,
-train).  Additions: batch data parallelism when launched under torchrun (each rank trains on
-its shard of every batch; one flat-gradient all-reduce per step, see training.py), and
-``resume(path)`` (the reference only saves).
+train).  Additions: batch data parallelism when launched under torchrun (each rank loads and trains on
+its shard of every batch; one flat-gradient all-reduce per step, see training.py; validation batches
+are dealt out over the ranks), and ``resume(path)`` (the reference only saves).
 
 Kept from the reference on purpose: the optimizer is built before the generator's lazy upsample
 blocks exist, so those blocks receive gradients and count in the clip norm but are not updated
@@ -46,6 +46,37 @@ def shard_bounds(n, rank, world):
     if n < world:
         return None
     return rank * n // world, (rank + 1) * n // world
+
+
+class ShardedBatchSampler:
+    """Data parallelism at the loader: wraps a batch sampler and yields, on every rank, only this rank's slice
+    of each batch's indices (shard_bounds), so a rank loads and copies to its GPU just the samples it trains on.
+    Batches with fewer samples than ranks are dropped by all ranks alike.  A shuffling base sampler must draw
+    the same permutation on every rank: give it a generator with the same seed everywhere."""
+
+    def __init__(self, batch_sampler, rank, world):
+        self.batch_sampler, self.rank, self.world = batch_sampler, rank, world
+
+    def __iter__(self):
+        for idx in self.batch_sampler:
+            bounds = shard_bounds(len(idx), self.rank, self.world)
+            if bounds is not None:
+                yield idx[bounds[0]:bounds[1]]
+
+    def __len__(self):
+        return len(self.batch_sampler)
+
+
+def sum_over_ranks(values):
+    """Element-wise sum of a short list of host numbers over the ranks (identity for one process)."""
+    rank, world = _rank_world()
+    if world == 1:
+        return [float(v) for v in values]
+    t = torch.tensor([float(v) for v in values], dtype=torch.float64)
+    if dist.get_backend() == "nccl":
+        t = t.cuda()
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return [float(v) for v in t.cpu()]
 
 
 def mean_over_ranks(x):
@@ -89,14 +120,25 @@ class Trainer:
                 parts = split_dataset_by_year(full, tuple(tr.train_years), tuple(tr.val_years), tuple(tr.test_years))
             else:
                 parts = split_dataset_random(full, 0.7, 0.15, 0.15)
-            self.train_loader = DataLoader(parts[0], batch_size=tr.batch_size, shuffle=True)
+            self.train_loader = self._train_loader(parts[0], tr.batch_size)
             self.val_loader = DataLoader(parts[1], batch_size=tr.batch_size, shuffle=False)
             self.test_loader = DataLoader(parts[2], batch_size=tr.batch_size, shuffle=False)
         else:
-            self.train_loader = DataLoader(full, batch_size=tr.batch_size, shuffle=True)
+            self.train_loader = self._train_loader(full, tr.batch_size)
             self.val_loader = self.test_loader = None
         self.dataloader = self.train_loader
         return full
+
+    def _train_loader(self, dataset, batch_size):
+        """The reference's shuffled loader (trainer.py:94-108).  Under data parallelism every rank walks the same
+        shuffled batches (one seed for all ranks) but loads only its own slice of each."""
+        rank, world = _rank_world()
+        seed = os.environ.get("PLC_SHUFFLE_SEED")
+        if world == 1 and seed is None:
+            return DataLoader(dataset, batch_size=batch_size, shuffle=True)     # unseeded, as the reference
+        from torch.utils.data import BatchSampler, RandomSampler
+        order = RandomSampler(dataset, generator=torch.Generator().manual_seed(int(seed or "0")))
+        return DataLoader(dataset, batch_sampler=ShardedBatchSampler(BatchSampler(order, batch_size, drop_last=False), rank, world))
 
     # ------------------------------------------------------------------ model
     def setup_model(self, dataset):
@@ -110,11 +152,9 @@ class Trainer:
         rank, world = _rank_world()
         if world > 1:
             torch.manual_seed(0)      # identical initial weights on every rank
-        self.model = Generator(**kw).to(self.device)
+        self.model = self._make_model(**kw).to(self.device)
         tr = self.config.training
-        # Adam as the reference (trainer.py:153-158); FusedAdam keeps torch.optim.Adam's state_dict layout
-        from ..optim import FusedAdam
-        self.optimizer = FusedAdam(self.model.parameters(), lr=tr.learning_rate)
+        self.optimizer = self._make_optimizer(self.model.parameters(), tr.learning_rate)
         self.scheduler = torch.optim.lr_scheduler.ReduceLROnPlateau(self.optimizer, mode="min", factor=tr.scheduler_factor,
                                                                     patience=tr.scheduler_patience)
         self.loss_module = CombinedLoss(lambda_point=tr.lambda_point, lambda_conserve=tr.lambda_conserve,
@@ -122,23 +162,21 @@ class Trainer:
                                         use_weighted_loss=getattr(tr, "use_weighted_loss", True),
                                         weight_strategy=getattr(tr, "weight_strategy", "log"))
 
+    # (the two objects a test without a GPU replaces by CPU stand-ins)
+    def _make_model(self, **kw):
+        return Generator(**kw)
+
+    def _make_optimizer(self, params, lr):
+        # Adam as the reference (trainer.py:153-158); FusedAdam keeps torch.optim.Adam's state_dict layout
+        from ..optim import FusedAdam
+        return FusedAdam(params, lr=lr)
+
     def _forward_kwargs(self):
         igs = getattr(self.config.model, "input_grid_size", None)
         return {"input_grid_size": tuple(igs)} if igs else {}
 
     def _to_device(self, batch):
         return tuple(t.to(self.device) for t in batch)
-
-    def _shard(self, batch):
-        """This rank's slice of a batch (data parallelism; identity for a single process), or None
-        when the batch is shorter than the number of ranks and is skipped by all of them."""
-        rank, world = _rank_world()
-        if world == 1:
-            return batch
-        bounds = shard_bounds(batch[0].shape[0], rank, world)
-        if bounds is None:
-            return None
-        return tuple(t[bounds[0]:bounds[1]] for t in batch)
 
     # ------------------------------------------------------------------ evaluation
     def compute_station_rmse(self, fake_hr, s_coords, s_values, scale_factor=1.0):
@@ -158,12 +196,19 @@ class Trainer:
         return rmse, at, truth, inside, seen
 
     def validate(self):
+        """trainer.py:182-223: mean over the validation batches of the batch loss and the batch RMSE.  Under data
+        parallelism the BATCHES are dealt out over the ranks (rank r evaluates batches r, r + world, ...: every
+        batch is evaluated whole, exactly as a single process would) and the sums and counts are added over
+        the ranks, so every rank gets the same two means."""
         if self.val_loader is None:
             return None
+        rank, world = _rank_world()
         self.model.eval()
         losses, rmses = [], []
         with torch.no_grad():
-            for batch in self.val_loader:
+            for k, batch in enumerate(self.val_loader):
+                if k % world != rank:
+                    continue
                 lr, dem, lu, s_coords, s_values = self._to_device(batch)
                 fake_hr = self.model(lr, dem, lu, **self._forward_kwargs())
                 sf = fake_hr.shape[-2] / lr.shape[-2]
@@ -171,7 +216,8 @@ class Trainer:
                 losses.append(loss.item())
                 rmses.append(self.compute_station_rmse(fake_hr, s_coords, s_values, sf)[0].item())
         self.model.train()
-        return {"loss": np.mean(losses), "rmse": np.mean(rmses)}
+        loss_sum, rmse_sum, n = sum_over_ranks([float(np.sum(losses)), float(np.sum(rmses)), len(losses)])
+        return {"loss": loss_sum / n, "rmse": rmse_sum / n} if n else {"loss": float("nan"), "rmse": float("nan")}
 
     # ------------------------------------------------------------------ training
     def train_epoch(self, epoch, T):
@@ -180,10 +226,9 @@ class Trainer:
         sums = {k: [] for k in ("total", "point", "conserve", "smooth", "temporal")}
         last = (None, None, None, None)
         for i, batch in enumerate(self.train_loader):
-            shard = self._shard(self._to_device(batch))
-            if shard is None:          # fewer samples than ranks: every rank skips (same decision everywhere)
-                continue
-            lr, dem, lu, s_coords, s_values = shard
+            # (under data parallelism the loader already yields this rank's slice of the batch, and drops batches
+            # with fewer samples than ranks on every rank alike: ShardedBatchSampler)
+            lr, dem, lu, s_coords, s_values = self._to_device(batch)
             loss, parts, fake_hr, skipped = train_step(
                 self.model, self.loss_module, self.optimizer, lr, dem, lu, s_coords, s_values,
                 max_norm=self.config.training.grad_clip_norm, forward_kwargs=self._forward_kwargs(),
@@ -256,7 +301,7 @@ class Trainer:
             self.history["rmse"].append(train_rmse)
             self.history["learning_rate"].append(self.optimizer.param_groups[0]["lr"])
             val = self.validate()
-            current = float(val["rmse"]) if val else train_rmse     # validation runs whole on every rank: identical
+            current = float(val["rmse"]) if val else train_rmse     # (the same number on every rank: see validate)
             if rank == 0:
                 print(f"Epoch {epoch} | Train RMSE: {train_rmse:.4f}" +
                       (f" | Val Loss: {val['loss']:.4f} | Val RMSE: {val['rmse']:.4f}" if val else ""))

@@ -220,3 +220,82 @@ def test_dp_nan_on_one_rank_with_parameters_outside_the_optimizer(tmp_path):
     # the un-owned parameters never move
     for a, b in zip(r[0]["params"][0][2:], r[0]["params"][3][2:]):
         assert torch.equal(a, b)
+
+
+def _trainer_worker(rank, world, port, cfg_dir, out_dir):
+    """The host Trainer with CPU stand-ins for the GPU-only model and optimizer, over gloo."""
+    os.environ["PLC_SHUFFLE_SEED"] = "3"
+    if world > 1:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    from pl_convlstm_gan_amd.host import config as C
+    from pl_convlstm_gan_amd.host import trainer as TR
+    C.CONFIG_DIR = cfg_dir
+
+    class Upsampling(TinyRollout):
+        def __init__(self, lu_channels=5, **kw):
+            super().__init__()
+            self.gate = nn.Conv2d(1 + lu_channels, 1, 1)
+            self.upsample_blocks = None
+
+        def forward(self, rain_lr, dem, lu, input_grid_size=None):
+            B, T, C, H, W = rain_lr.shape
+            y = self.conv(rain_lr.reshape(B * T, C, H, W))
+            y = torch.nn.functional.interpolate(y, size=dem.shape[-2:], mode="nearest").reshape(B, T, 1, *dem.shape[-2:])
+            g = torch.sigmoid(self.gate(torch.cat((dem, lu), dim=1))).unsqueeze(1)
+            return y * g
+
+    class CpuTrainer(TR.Trainer):
+        def _make_model(self, **kw):
+            torch.manual_seed(0)
+            return Upsampling(lu_channels=kw["lu_channels"])
+
+        def _make_optimizer(self, params, lr):
+            return torch.optim.Adam(params, lr=lr)
+
+    t = CpuTrainer("synthetic")
+    t.device = torch.device("cpu")
+    t.train()
+    seen = sum(len(idx) for idx in t.train_loader.batch_sampler) if world > 1 else None
+    torch.save({"history": {k: [float(x) for x in v] for k, v in t.history.items()}, "seen": seen,
+                "params": [p.detach().clone() for p in t.model.parameters()]}, os.path.join(out_dir, f"w{world}_rank{rank}.pt"))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def test_trainer_history_is_identical_on_every_rank(tmp_path):
+    """The host Trainer under data parallelism (two ranks over gloo, CPU stand-ins for model and optimizer): every
+    rank loads only its slice of each shuffled batch, validation batches are dealt out over the ranks, and both
+    ranks end with the same history, the same decisions and the same parameters -- which also equal a single
+    process's run over the same shuffled batches up to floating-point summation order."""
+    from pl_convlstm_gan_amd.host import config as C
+    from pl_convlstm_gan_amd.host.datasets import write_synthetic_dataset
+    paths = write_synthetic_dataset(str(tmp_path / "basin"), start_year=2012, end_year=2013, lr_hw=(6, 5), scale=2,
+                                    n_stations=6)
+    cfg = C.Config()
+    for k, v in paths.items():
+        setattr(cfg.data, k, v)
+    cfg.model.scale_factor = 2
+    cfg.training.batch_size = 64
+    cfg.training.epochs = 2
+    cfg.training.train_years, cfg.training.val_years, cfg.training.test_years = [2012, 2012], [2013, 2013], [2013, 2013]
+    cfg.output.output_dir = str(tmp_path / "out")
+    cfg.output.log_interval = 1000
+    cfg_dir = tmp_path / "configs"
+    cfg.to_yaml(str(cfg_dir / "synthetic.yaml"))
+    mp.spawn(_trainer_worker, args=(2, _free_port(), str(cfg_dir), str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_trainer_worker, args=(1, 0, str(cfg_dir), str(tmp_path)), nprocs=1, join=True)
+    r0, r1 = (torch.load(tmp_path / f"w2_rank{i}.pt", weights_only=True) for i in range(2))
+    one = torch.load(tmp_path / "w1_rank0.pt", weights_only=True)
+    assert r0["history"] == r1["history"] and r0["history"]["epoch"] == [0.0, 1.0]
+    for a, b in zip(r0["params"], r1["params"]):
+        assert torch.equal(a, b)
+    n_train = 366 - 5
+    assert r0["seen"] + r1["seen"] == n_train and abs(r0["seen"] - r1["seen"]) <= 6     # each rank loads its own half only
+    # against the single process: what the ranks decide on (validation RMSE, learning rate) and where training ends.
+    # (the TRAIN loss / RMSE columns are means of per-rank batch figures, i.e. means over half batches, and agree
+    # only approximately)
+    for a, b in zip(one["params"], r0["params"]):
+        assert torch.allclose(a, b, atol=1e-6, rtol=1e-4)
+    assert one["history"]["learning_rate"] == r0["history"]["learning_rate"]
