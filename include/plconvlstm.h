@@ -86,7 +86,10 @@ int plc_pack_conv_weight(const float* w, const float* bias, void* wpk, float* bp
  *   wpk/bpk from plc_pack_conv_weight(mode = PLC_PACK_LSTM).
  * plc_convlstm_cell_fwd: boundary layout (NCHW fp32) in and out; `workspace` must hold
  *   plc_convlstm_cell_workspace_bytes(...) bytes.
- * Supported: Cin, Ch multiples of 8 with (Cin, Ch) in {(16,16), (16,32)}.
+ * The CB8 form takes whole 8-channel blocks (Cin, Ch multiples of 8; (16,16) and (16,32) run on weight-stationary
+ * instantiations, others on the run-time-width kernel).  The boundary form takes ANY Cin, Ch > 0, as the
+ * reference's ConvLSTMCell does: widths that are not multiples of 8 are carried as the next multiple with zero
+ * channels (plc_pack_conv_weight emits zero rows, columns and biases for them, which keeps them zero).
  * ------------------------------------------------------------------------------------- */
 int plc_convlstm_cell_fwd_cb8(const void* x, const void* h, const float* c_in,
                               const void* wpk, const float* bpk,

@@ -43,6 +43,10 @@ static int plc_fail(int code, const char* fmt, ...) {
 static inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+// Channel counts inside the engine are whole 8-channel blocks: a width that is not a multiple of 8 is carried
+// with zero channels up to the next multiple (zero weights and biases keep them zero through every layer: a
+// padding channel of a ConvLSTM cell has i = f = o = 1/2, g = 0, hence c = h = 0 for ever).
+static inline int pad8(int c) { return (c + 7) & ~7; }
 
 extern "C" int plc_version(void) { return PLC_VERSION; }
 extern "C" const char* plc_last_error(void) { return g_err; }
@@ -78,8 +82,7 @@ extern "C" int plc_cb8_bf16_to_nchw_f32(const void* src, float* dst, int N, int 
 static int state_layout(const float* src, float* dst, int N, int C, int H, int W, int dir, void* stream,
                         const char* who) {
     PLC_REQUIRE(src && dst && N > 0 && C > 0 && H > 0 && W > 0, "%s: bad argument", who);
-    PLC_REQUIRE(C % 8 == 0, "%s: channel count %d is not a multiple of 8", who, C);
-    const long long total = (long long)N * C * H * W;
+    const long long total = (long long)N * pad8(C) * H * W;
     hipLaunchKernelGGL(plc_state_layout_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream,
                        src, dst, N, C, H, W, dir);
     PLC_HIP(hipGetLastError());
@@ -169,11 +172,11 @@ extern "C" int plc_pack_conv_weight(const float* w, const float* bias, void* wpk
     PLC_REQUIRE(w && wpk && bpk, "plc_pack_conv_weight: null pointer");
     PLC_REQUIRE(cout > 0 && c0 > 0 && c1 >= 0 && (ks == 1 || ks == 3), "plc_pack_conv_weight: bad shape");
     PLC_REQUIRE(mode >= 0 && mode <= 2, "plc_pack_conv_weight: bad mode %d", mode);
-    if (mode != PLC_PACK_PLAIN) PLC_REQUIRE(cout % 32 == 0, "plc_pack_conv_weight: cout %d must be a multiple of 32 for mode %d", cout, mode);
+    if (mode != PLC_PACK_PLAIN) PLC_REQUIRE(cout % 4 == 0, "plc_pack_conv_weight: cout %d must be a multiple of 4 for mode %d", cout, mode);
     PLC_REQUIRE(aligned16(wpk) && aligned16(bpk), "plc_pack_conv_weight: packed buffers must be 16-byte aligned");
     // a ConvLSTM gate conv of a width without a weight-stationary instantiation runs on the
     // run-time-width kernel, which wants its own K order (plc_convlstm_cell_fwd_cb8 makes the same choice)
-    const PackJob jb = pack_job(w, bias, wpk, bpk, cout, c0, c1, ks, mode, mode == PLC_PACK_LSTM && !cell_fast(c0, c1));
+    const PackJob jb = pack_job(w, bias, wpk, bpk, cout, c0, c1, ks, mode, mode == PLC_PACK_LSTM && !cell_fast(pad8(c0), pad8(c1)));
     hipLaunchKernelGGL(plc_pack_weight_kernel, dim3(jb.n_blocks), dim3(256), 0, (hipStream_t)stream, jb);
     PLC_HIP(hipGetLastError());
     return PLC_OK;
@@ -183,27 +186,35 @@ extern "C" int plc_pack_conv_weight(const float* w, const float* bias, void* wpk
 // channels split over `ksplit` waves.
 static inline int packT_nmt(int c0, int c1) { return cdiv(8 * pack_ncb(c0, c1), 32); }
 static inline int packT_nks(int cout, int ks, int ksplit) { return (ks * ks * (cdiv(cout, 8) / ksplit) + 1) / 2; }
+// K blocks of a data-gradient conv: those of its dz tensor.  An LSTM gate conv's dz is gate-major with every gate
+// padded to whole blocks (lstm_k = its real hidden channels); k_blocks > 0 overrides (a dz wider than the conv's outputs).
+static inline int packT_kblocks(int cout, int lstm_k, int k_blocks) {
+    return k_blocks > 0 ? k_blocks : (lstm_k > 0 ? 4 * cdiv(lstm_k, 8) : cdiv(cout, 8));
+}
 static size_t packedT_weight_bytes(int cout, int c0, int c1, int ks, int ksplit) {
     const size_t plain = (size_t)ksplit * packT_nks(cout, ks, ksplit), chunked = (size_t)plc_g_nks(cdiv(cout, 8), ks);
     return align256((size_t)packT_nmt(c0, c1) * (plain > chunked ? plain : chunked) * 64 * 16);
 }
+// (cout, c0, c1: the conv's REAL channel counts)
 static PackJob pack_job_T(const float* w, void* wpk, float* bpk, int cout, int c0, int c1, int ks, int ksplit,
-                          int generic = 0) {
+                          int generic = 0, int lstm_k = 0, int k_blocks = 0) {
     PackJob jb;
     memset(&jb, 0, sizeof(jb));
     jb.w = w; jb.wpk = (unsigned short*)wpk; jb.bpk = bpk;
     jb.cout = cout; jb.c0 = c0; jb.c1 = c1; jb.ks = ks;
+    jb.lstm_k = lstm_k;
+    jb.k_blocks = packT_kblocks(cout, lstm_k, k_blocks);
     if (generic) ksplit = 1;
     jb.n_mt = packT_nmt(c0, c1);
-    jb.nks_w = generic ? plc_g_nks(cdiv(cout, 8), ks) : packT_nks(cout, ks, ksplit);
+    jb.nks_w = generic ? plc_g_nks(jb.k_blocks, ks) : packT_nks(8 * jb.k_blocks, ks, ksplit);
     jb.chunk = generic ? PLC_G_CHUNK : 0;
     jb.transposed = 1; jb.ksplit = ksplit;
     jb.n_blocks = pack_blocks((long long)jb.n_mt * ksplit * jb.nks_w * 512);
     return jb;
 }
 static int pack_conv_weight_T(const float* w, void* wpk, float* bpk, int cout, int c0, int c1, int ks, int ksplit,
-                              hipStream_t st, int generic = 0) {
-    const PackJob jb = pack_job_T(w, wpk, bpk, cout, c0, c1, ks, ksplit, generic);
+                              hipStream_t st, int generic = 0, int lstm_k = 0) {
+    const PackJob jb = pack_job_T(w, wpk, bpk, cout, c0, c1, ks, ksplit, generic, lstm_k);
     hipLaunchKernelGGL(plc_pack_weight_kernel, dim3(jb.n_blocks), dim3(256), 0, st, jb);
     PLC_HIP(hipGetLastError());
     return PLC_OK;
@@ -712,8 +723,6 @@ extern "C" int plc_convlstm_cell_fwd(const float* x, const float* h, const float
     PLC_REQUIRE(x && h && c && weight && h_next && c_next && workspace, "plc_convlstm_cell_fwd: null pointer");
     PLC_REQUIRE(B > 0 && Cin > 0 && Ch > 0 && H > 0 && W > 0, "plc_convlstm_cell_fwd: non-positive size");
     PLC_REQUIRE(((uintptr_t)workspace & 255) == 0, "plc_convlstm_cell_fwd: workspace must be 256-byte aligned");
-    if (Cin % 8 != 0 || Ch % 8 != 0)
-        return plc_fail(PLC_EUNSUPPORTED, "ConvLSTM cell (Cin=%d, Ch=%d): channel counts must be multiples of 8", Cin, Ch);
     const CellWs s = cell_ws(B, Cin, Ch, H, W);
     if (workspace_bytes < s.total)
         return plc_fail(PLC_EWORKSPACE, "plc_convlstm_cell_fwd: workspace %zu < %zu bytes", workspace_bytes, s.total);
@@ -725,8 +734,10 @@ extern "C" int plc_convlstm_cell_fwd(const float* x, const float* h, const float
     if ((rc = plc_pack_conv_weight(weight, bias, ws + s.wpk, (float*)(ws + s.bpk), 4 * Ch, Cin, Ch, 3,
                                    PLC_PACK_LSTM, stream)))
         return rc;
+    // (widths that are not multiples of 8 run as the next multiple: the conversions above padded with zeros, the
+    // packed weights and biases of the padding channels are zero)
     if ((rc = cell_fwd_cb8(ws + s.x, ws + s.h, (float*)(ws + s.c), ws + s.wpk, (float*)(ws + s.bpk), ws + s.ho,
-                           (float*)(ws + s.co), nullptr, B, Cin, Ch, H, W, (hipStream_t)stream)))
+                           (float*)(ws + s.co), nullptr, B, pad8(Cin), pad8(Ch), H, W, (hipStream_t)stream)))
         return rc;
     if ((rc = plc_cb8_bf16_to_nchw_f32(ws + s.ho, h_next, B, Ch, H, W, stream))) return rc;
     if ((rc = plc_cb8_f32_to_nchw_f32((float*)(ws + s.co), c_next, B, Ch, H, W, stream))) return rc;
@@ -894,11 +905,12 @@ static int rollout_plan(const plc_rollout_desc* d, RolloutPlan* p) {
     PLC_REQUIRE(d->B > 0 && d->T > 0 && d->H > 0 && d->W > 0, "rollout: non-positive B/T/H/W");
     PLC_REQUIRE(d->L > 0 && d->L <= 16, "rollout: lu_channels=%d unsupported (1..16)", d->L);
     PLC_REQUIRE(d->n_blocks >= 0 && d->n_blocks <= 8, "rollout: n_blocks=%d out of range", d->n_blocks);
-    if (d->C1 <= 0 || d->C2 <= 0 || d->C1 % 8 != 0 || d->C2 % 8 != 0 || d->C1 > 512 || d->C2 > 512)
-        return plc_fail(PLC_EUNSUPPORTED, "rollout: hidden_dims=[%d,%d]: both must be multiples of 8 (at most 512)",
+    if (d->C1 <= 0 || d->C2 < 2 || d->C1 > 512 || d->C2 > 512)
+        return plc_fail(PLC_EUNSUPPORTED, "rollout: hidden_dims=[%d,%d]: the first must be 1..512, the second 2..512",
                         d->C1, d->C2);
     PLC_REQUIRE(d->dem_H > 0 && d->dem_W > 0 && d->lu_H > 0 && d->lu_W > 0, "rollout: bad aux size");
-    const int C1 = d->C1, C2 = d->C2, B = d->B, T = d->T;
+    // C1, C2: the widths as the engine carries them (whole 8-channel blocks); R1, R2: the model's own
+    const int C1 = pad8(d->C1), C2 = pad8(d->C2), R1 = d->C1, R2 = d->C2, B = d->B, T = d->T;
     const size_t hw = (size_t)d->H * d->W;
     p->up_H = d->H << d->n_blocks;
     p->up_W = d->W << d->n_blocks;
@@ -912,15 +924,15 @@ static int rollout_plan(const plc_rollout_desc* d, RolloutPlan* p) {
         q.b = take(plc_packed_bias_bytes(cout));
         return q;
     };
-    p->init = pk(C1, 3, 0, 3);
-    p->cell1 = pk(4 * C1, C1, C1, 3);
-    p->cell2 = pk(4 * C2, C1, C2, 3);
-    p->dem0 = pk(C2 / 2, 1, 0, 3);
-    p->dem2 = pk(C2, C2 / 2, 0, 1);
-    p->lu0 = pk(C2 / 2, d->L, 0, 3);
-    p->lu2 = pk(C2, C2 / 2, 0, 1);
-    for (int k = 0; k < d->n_blocks; ++k) p->up[k] = pk(4 * C2, C2, 0, 3);
-    p->post0 = pk(32, C2, 0, 3);
+    p->init = pk(R1, 3, 0, 3);
+    p->cell1 = pk(4 * R1, R1, R1, 3);
+    p->cell2 = pk(4 * R2, R1, R2, 3);
+    p->dem0 = pk(R2 / 2, 1, 0, 3);
+    p->dem2 = pk(R2, R2 / 2, 0, 1);
+    p->lu0 = pk(R2 / 2, d->L, 0, 3);
+    p->lu2 = pk(R2, R2 / 2, 0, 1);
+    for (int k = 0; k < d->n_blocks; ++k) p->up[k] = pk(4 * R2, R2, 0, 3);
+    p->post0 = pk(32, R2, 0, 3);
     p->post2 = pk(1, 32, 0, 3);
     p->img1 = (size_t)(C1 / 8) * hw * 16;
     p->img2 = (size_t)(C2 / 8) * hw * 16;
@@ -951,16 +963,16 @@ static int rollout_plan(const plc_rollout_desc* d, RolloutPlan* p) {
     } else p->fin = cur;
     p->dem_hr = take((size_t)B * 1 * ohw * 16);
     p->lu_hr = take((size_t)B * cdiv(d->L, 8) * ohw * 16);
-    p->dem_mid = take((size_t)B * cdiv(C2 / 2, 8) * ohw * 16);
-    p->lu_mid = take((size_t)B * cdiv(C2 / 2, 8) * ohw * 16);
+    p->dem_mid = take((size_t)B * cdiv(R2 / 2, 8) * ohw * 16);
+    p->lu_mid = take((size_t)B * cdiv(R2 / 2, 8) * ohw * 16);
     p->gate_dem = take((size_t)B * (C2 / 8) * ohw * 16);
     p->gate_lu = d->save_for_backward ? take((size_t)B * (C2 / 8) * ohw * 16) : (size_t)-1;
     p->gate = take((size_t)B * (C2 / 8) * ohw * 16);
     p->p0 = take((size_t)T * B * 4 * ohw * 16);
     p->sync = take(256);
     if (d->gate_fp8) {
-        if (!widths_fast(C1, C2))
-            return plc_fail(PLC_EUNSUPPORTED, "rollout: the fp8 gate conv is compiled for hidden_dims=[16,32] only (got [%d,%d])", C1, C2);
+        if (!widths_fast(R1, R2))
+            return plc_fail(PLC_EUNSUPPORTED, "rollout: the fp8 gate conv is compiled for hidden_dims=[16,32] only (got [%d,%d])", R1, R2);
         p->xs8 = take((size_t)T * B * (C1 / 16) * hw * 16);
         p->h1s8 = take((size_t)(T + 1) * B * (C1 / 16) * hw * 16);
         p->h2s8 = take((size_t)(T + 1) * B * (C2 / 16) * hw * 16);
@@ -1015,7 +1027,9 @@ extern "C" int plc_generator_rollout_fwd(const plc_rollout_desc* d, void* stream
     hipStream_t st = (hipStream_t)stream;
     ForkGuard forks(st);         // joins the auxiliary streams on an early (error) return too
     char* ws = (char*)d->workspace;
-    const int B = d->B, T = d->T, H = d->H, W = d->W, C1 = d->C1, C2 = d->C2, L = d->L;
+    // C1, C2: the widths as whole 8-channel blocks (what every buffer and kernel sees); R1, R2: the model's own
+    // widths (what the weight packers see: the padding rows and columns they emit are zero)
+    const int B = d->B, T = d->T, H = d->H, W = d->W, C1 = pad8(d->C1), C2 = pad8(d->C2), R1 = d->C1, R2 = d->C2, L = d->L;
     const int oH = d->out_H, oW = d->out_W;
     const long long hw = (long long)H * W, ohw = (long long)oH * oW;
 
@@ -1030,16 +1044,16 @@ extern "C" int plc_generator_rollout_fwd(const plc_rollout_desc* d, void* stream
     auto pack = [&](const float* w, const float* b, const Packed& q, int cout, int c0, int c1, int ks, int mode, int g) {
         return pack_batch_add(&batch, pack_job(w, b, ws + q.w, (float*)(ws + q.b), cout, c0, c1, ks, mode, g), st);
     };
-    if ((rc = pack(d->init_w, d->init_b, p.init, C1, 3, 0, 3, PLC_PACK_PLAIN, 0))) return rc;
-    if ((rc = pack(d->cell1_w, d->cell1_b, p.cell1, 4 * C1, C1, C1, 3, PLC_PACK_LSTM, !cell_fast(C1, C1)))) return rc;
-    if ((rc = pack(d->cell2_w, d->cell2_b, p.cell2, 4 * C2, C1, C2, 3, PLC_PACK_LSTM, !cell_fast(C1, C2)))) return rc;
-    if ((rc = pack(d->dem0_w, d->dem0_b, p.dem0, C2 / 2, 1, 0, 3, PLC_PACK_PLAIN, 0))) return rc;
-    if ((rc = pack(d->dem2_w, d->dem2_b, p.dem2, C2, C2 / 2, 0, 1, PLC_PACK_PLAIN, gen))) return rc;
-    if ((rc = pack(d->lu0_w, d->lu0_b, p.lu0, C2 / 2, L, 0, 3, PLC_PACK_PLAIN, 0))) return rc;
-    if ((rc = pack(d->lu2_w, d->lu2_b, p.lu2, C2, C2 / 2, 0, 1, PLC_PACK_PLAIN, gen))) return rc;
+    if ((rc = pack(d->init_w, d->init_b, p.init, R1, 3, 0, 3, PLC_PACK_PLAIN, 0))) return rc;
+    if ((rc = pack(d->cell1_w, d->cell1_b, p.cell1, 4 * R1, R1, R1, 3, PLC_PACK_LSTM, !cell_fast(C1, C1)))) return rc;
+    if ((rc = pack(d->cell2_w, d->cell2_b, p.cell2, 4 * R2, R1, R2, 3, PLC_PACK_LSTM, !cell_fast(C1, C2)))) return rc;
+    if ((rc = pack(d->dem0_w, d->dem0_b, p.dem0, R2 / 2, 1, 0, 3, PLC_PACK_PLAIN, 0))) return rc;
+    if ((rc = pack(d->dem2_w, d->dem2_b, p.dem2, R2, R2 / 2, 0, 1, PLC_PACK_PLAIN, gen))) return rc;
+    if ((rc = pack(d->lu0_w, d->lu0_b, p.lu0, R2 / 2, L, 0, 3, PLC_PACK_PLAIN, 0))) return rc;
+    if ((rc = pack(d->lu2_w, d->lu2_b, p.lu2, R2, R2 / 2, 0, 1, PLC_PACK_PLAIN, gen))) return rc;
     for (int k = 0; k < d->n_blocks; ++k)
-        if ((rc = pack(d->up_w[k], d->up_b[k], p.up[k], 4 * C2, C2, 0, 3, PLC_PACK_PIXSHUF, gen))) return rc;
-    if ((rc = pack(d->post0_w, d->post0_b, p.post0, 32, C2, 0, 3, PLC_PACK_PLAIN, gen))) return rc;
+        if ((rc = pack(d->up_w[k], d->up_b[k], p.up[k], 4 * R2, R2, 0, 3, PLC_PACK_PIXSHUF, gen))) return rc;
+    if ((rc = pack(d->post0_w, d->post0_b, p.post0, 32, R2, 0, 3, PLC_PACK_PLAIN, gen))) return rc;
     if ((rc = pack(d->post2_w, d->post2_b, p.post2, 1, 32, 0, 3, PLC_PACK_PLAIN, 0))) return rc;
     if ((rc = pack_batch_flush(&batch, st))) return rc;
 
@@ -1063,7 +1077,7 @@ extern "C" int plc_generator_rollout_fwd(const plc_rollout_desc* d, void* stream
                            (uint4*)(ws + p.lu_hr), B, L, d->lu_H, d->lu_W, oH, oW, 1,
                            (float)d->lu_H / (float)oH, (float)d->lu_W / (float)oW);
         PLC_HIP(hipGetLastError());
-        const int mcb = cdiv(C2 / 2, 8);
+        const int mcb = cdiv(R2 / 2, 8);
         ConvArgs a = conv_args(oH, oW, B);
         a.src0 = tens(ws + p.dem_hr, ohw * 16, 0);
         a.out0 = tens(ws + p.dem_mid, mcb * ohw * 16, 0);

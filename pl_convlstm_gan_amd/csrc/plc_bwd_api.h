@@ -59,9 +59,13 @@ static int arena_flush(SlabArena* ar, hipStream_t st) {
 
 // `in` carries H, W, n_in and the staging tensors of the conv input; dz has mcb_valid channel blocks.
 template <int NCB0, int NCB1, int MT, int KS, int STAGE>
+// cout: dz channels (= slab rows) this launch covers; c0, c1: REAL channel counts of the two conv inputs.
+// row_off / cout_total / lstm_ch: where those rows sit among the conv's outputs (FinalizeJob); cout_total = 0 means
+// the launch covers the whole conv (cout_total = cout).
 static int launch_wgrad(ConvArgs in, PlcTensor dz, int mcb_valid, int n_img, SlabArena* ar,
                         float* dw, float* db, int cout, int c0, int c1, hipStream_t st,
-                        const PlcTensor* dz_mask = nullptr, int ci_off = 0, int c_total = 0) {
+                        const PlcTensor* dz_mask = nullptr, int ci_off = 0, int c_total = 0, int row_off = 0,
+                        int cout_total = 0, int lstm_ch = 0) {
     using G = WgradGeom<NCB0 + NCB1, MT, KS>;
     if (dz_mask && STAGE == STAGE_CB8)
         return plc_fail(PLC_EUNSUPPORTED, "wgrad: the plain CB8 staging does not load a dz mask");
@@ -125,6 +129,7 @@ static int launch_wgrad(ConvArgs in, PlcTensor dz, int mcb_valid, int n_img, Sla
     jb.n_slabs = grid; jb.rows_pad = MT * 32; jb.cols_pad = G::NT * 32;
     jb.cout = cout; jb.c0 = c0; jb.c1 = c1; jb.ks = KS; jb.ncb = NCB0 + NCB1;
     jb.ci_off = ci_off; jb.c_total = c_total > 0 ? c_total : c0 + c1;
+    jb.row_off = row_off; jb.cout_total = cout_total > 0 ? cout_total : cout; jb.lstm_ch = lstm_ch;
     const long long groups = ((long long)cout * G::NT * 32 + 31) / 32;      // 32 output elements per block pass
     jb.n_blocks = (int)(groups < 1 ? 1 : (groups > 1024 ? 1024 : groups));
     jb.first_block = ar->blocks;
@@ -168,6 +173,7 @@ static int launch_wgrad_cout1(PlcTensor x, PlcTensor dy, int n_in, int H, int W,
     jb.n_slabs = grid; jb.rows_pad = 1; jb.cols_pad = W1_COLS;
     jb.cout = 1; jb.c0 = 32; jb.c1 = 0; jb.ks = 3; jb.ncb = 4;
     jb.ci_off = 0; jb.c_total = 32;
+    jb.row_off = 0; jb.cout_total = 1; jb.lstm_ch = 0;
     jb.n_blocks = W1_COLS / 32;
     jb.first_block = ar->blocks;
     ar->blocks += jb.n_blocks;
@@ -181,11 +187,14 @@ static int launch_wgrad_cout1(PlcTensor x, PlcTensor dy, int n_in, int H, int W,
 // scatters into its rectangle of dW (row offset by pointer, input-channel offset by ci_off).  dz is
 // re-read once per input chunk: the price of running widths that have no instantiation of their own.
 // in.zero_state != 0: src1 of the first n_in images is the unstored zero initial state.
+// c0, c1, cout: REAL channel counts.  lstm_ch > 0: dz is an LSTM gate conv's (gate-major, gates padded to whole
+// blocks; cout = 4 * lstm_ch), so its channel blocks number 4 * ceil(lstm_ch / 8).
 template <int NCBK, int MT, int KS, int STAGE>
 static int wgrad_chunked(const ConvArgs& in, int c0, int c1, PlcTensor dz, int cout, int n_img, SlabArena* ar,
-                         float* dw, float* db, hipStream_t st, const PlcTensor* dz_mask = nullptr) {
+                         float* dw, float* db, hipStream_t st, const PlcTensor* dz_mask = nullptr, int lstm_ch = 0) {
     const long long plane = (long long)in.H * in.W * 16;
-    const int taps = KS * KS, ctot = c0 + c1, mcb = cdiv(cout, 8);
+    const int ctot = c0 + c1, mcb = lstm_ch > 0 ? 4 * cdiv(lstm_ch, 8) : cdiv(cout, 8);
+    const int rows_all = lstm_ch > 0 ? 8 * mcb : cout;        // dz channel positions that the launches cover
     for (int mg = 0; mg * 4 * MT < mcb; ++mg) {
         PlcTensor dzg = dz, maskg;
         dzg.p += (long long)mg * 4 * MT * plane;
@@ -194,7 +203,7 @@ static int wgrad_chunked(const ConvArgs& in, int c0, int c1, PlcTensor dz, int c
             maskg.p += (long long)mg * 4 * MT * plane;
         }
         const int mcb_valid = mcb - mg * 4 * MT < 4 * MT ? mcb - mg * 4 * MT : 4 * MT;
-        const int rows = cout - mg * 32 * MT < 32 * MT ? cout - mg * 32 * MT : 32 * MT;
+        const int rows = rows_all - mg * 32 * MT < 32 * MT ? rows_all - mg * 32 * MT : 32 * MT;
         bool first = true;
         for (int src = 0; src < 2; ++src) {
             const int c_src = src == 0 ? c0 : c1, nb_src = cdiv(c_src, 8);
@@ -207,10 +216,9 @@ static int wgrad_chunked(const ConvArgs& in, int c0, int c1, PlcTensor dz, int c
                 ci.zero_state = (src == 1 && in.zero_state) ? 2 : 0;
                 ci.g_ncb0 = nb_src - cb < NCBK ? nb_src - cb : NCBK;
                 const int ch_here = c_src - 8 * cb < 8 * NCBK ? c_src - 8 * cb : 8 * NCBK;
-                int rc = launch_wgrad<NCBK, 0, MT, KS, STAGE>(ci, dzg, mcb_valid, n_img, ar,
-                                                              dw + (long long)mg * 32 * MT * ctot * taps,
-                                                              (first && db) ? db + mg * 32 * MT : nullptr, rows, ch_here, 0,
-                                                              st, dz_mask ? &maskg : nullptr, (src == 0 ? 0 : c0) + 8 * cb, ctot);
+                int rc = launch_wgrad<NCBK, 0, MT, KS, STAGE>(ci, dzg, mcb_valid, n_img, ar, dw, (first && db) ? db : nullptr,
+                                                              rows, ch_here, 0, st, dz_mask ? &maskg : nullptr,
+                                                              (src == 0 ? 0 : c0) + 8 * cb, ctot, mg * 32 * MT, cout, lstm_ch);
                 if (rc) return rc;
                 first = false;
             }
@@ -285,7 +293,7 @@ static int cell_dgrad(const void* dz, const void* wpkT, const float* bpk0, void*
                                 : launch_convr<16, 2, STAGE_CB8, EPI_ACT_CB8, 2, true>(a, B, 1, st);
     if (Cin % 8 == 0 && Ch % 8 == 0)
         return launch_convg<3, STAGE_CB8, EPI_ACT_CB8>(a, 4 * Ch / 8, 0, cdiv(Cin + Ch, 32), B, st);
-    return plc_fail(PLC_EUNSUPPORTED, "ConvLSTM cell backward (Cin=%d, Ch=%d): channel counts must be multiples of 8", Cin, Ch);
+    return plc_fail(PLC_EUNSUPPORTED, "ConvLSTM cell backward (Cin=%d, Ch=%d): padded channel counts expected", Cin, Ch);
 }
 static int cell_dgrad_ksplit(int Cin, int Ch) { return (Cin == 16 && Ch == 32) ? 2 : 1; }
 
@@ -356,8 +364,12 @@ static int cell_dgrad_pw_pair(const LstmBwdArgs& pw2, const ConvArgs& c2, const 
 
 // h0_zero: the first n_in images of `h` are the zero initial state and are not read (a rollout
 // does not store them).
+// Cin, Ch: the widths as whole blocks (what the tensors hold); Cin_r, Ch_r: the conv's own (0 = the same).
 static int cell_wgrad(const void* dz, PlcTensor x, PlcTensor h, int n_in, int n_img, SlabArena* slab,
-                      float* dw, float* db, int Cin, int Ch, int H, int W, hipStream_t st, bool h0_zero = false) {
+                      float* dw, float* db, int Cin, int Ch, int H, int W, hipStream_t st, bool h0_zero = false,
+                      int Cin_r = 0, int Ch_r = 0) {
+    if (Cin_r <= 0) Cin_r = Cin;
+    if (Ch_r <= 0) Ch_r = Ch;
     const long long hw = (long long)H * W;
     ConvArgs in = conv_args(H, W, n_in);
     in.src0 = x;
@@ -365,12 +377,14 @@ static int cell_wgrad(const void* dz, PlcTensor x, PlcTensor h, int n_in, int n_
     in.zero_state = h0_zero ? 1 : 0;
     PlcTensor dzt = tens(dz, (4 * Ch / 8) * hw * 16, (long long)n_in * (4 * Ch / 8) * hw * 16);
     if (Cin == 16 && Ch == 16)
-        return launch_wgrad<2, 2, 2, 3, STAGE_CB8>(in, dzt, 8, n_img, slab, dw, db, 64, 16, 16, st);
+        return launch_wgrad<2, 2, 2, 3, STAGE_CB8>(in, dzt, 8, n_img, slab, dw, db, 64, Cin_r, Ch_r, st, nullptr, 0, 0, 0,
+                                                   4 * Ch_r, Ch_r);
     if (Cin == 16 && Ch == 32)
-        return launch_wgrad<2, 4, 4, 3, STAGE_CB8>(in, dzt, 16, n_img, slab, dw, db, 128, 16, 32, st);
+        return launch_wgrad<2, 4, 4, 3, STAGE_CB8>(in, dzt, 16, n_img, slab, dw, db, 128, Cin_r, Ch_r, st, nullptr, 0, 0, 0,
+                                                   4 * Ch_r, Ch_r);
     if (Cin % 8 == 0 && Ch % 8 == 0)
-        return wgrad_chunked<4, 4, 3, STAGE_CB8>(in, Cin, Ch, dzt, 4 * Ch, n_img, slab, dw, db, st);
-    return plc_fail(PLC_EUNSUPPORTED, "ConvLSTM cell backward (Cin=%d, Ch=%d): channel counts must be multiples of 8", Cin, Ch);
+        return wgrad_chunked<4, 4, 3, STAGE_CB8>(in, Cin_r, Ch_r, dzt, 4 * Ch_r, n_img, slab, dw, db, st, nullptr, Ch_r);
+    return plc_fail(PLC_EUNSUPPORTED, "ConvLSTM cell backward (Cin=%d, Ch=%d): padded channel counts expected", Cin, Ch);
 }
 static size_t cell_wgrad_slab_bytes(int Cin, int Ch) {
     if (Cin == 16 && Ch == 16) return wgrad_slab_bytes<2, 2, 2, 3>();
@@ -387,6 +401,8 @@ struct CellBwdWs {
 };
 static CellBwdWs cell_bwd_ws(int B, int Cin, int Ch, int H, int W) {
     CellBwdWs s;
+    Cin = pad8(Cin);            // (the engine's widths are whole 8-channel blocks)
+    Ch = pad8(Ch);
     s.f = cell_ws(B, Cin, Ch, H, W);
     const size_t hw = (size_t)H * W;
     size_t o = s.f.total;
@@ -456,9 +472,11 @@ extern "C" int plc_convlstm_cell_bwd(const float* x, const float* h, const float
                 "plc_convlstm_cell_bwd: null pointer");
     PLC_REQUIRE(B > 0 && H > 0 && W > 0, "plc_convlstm_cell_bwd: non-positive size");
     PLC_REQUIRE(((uintptr_t)workspace & 255) == 0, "plc_convlstm_cell_bwd: workspace must be 256-byte aligned");
-    if (Cin <= 0 || Ch <= 0 || Cin % 8 != 0 || Ch % 8 != 0)
-        return plc_fail(PLC_EUNSUPPORTED, "ConvLSTM cell (Cin=%d, Ch=%d): channel counts must be multiples of 8", Cin, Ch);
+    PLC_REQUIRE(Cin > 0 && Ch > 0, "plc_convlstm_cell_bwd: non-positive channel count");
     const CellBwdWs s = cell_bwd_ws(B, Cin, Ch, H, W);
+    const int Cin_r = Cin, Ch_r = Ch;       // the cell's own widths; below Cin, Ch are the whole-block widths
+    Cin = pad8(Cin);
+    Ch = pad8(Ch);
     if (workspace_bytes < s.total)
         return plc_fail(PLC_EWORKSPACE, "plc_convlstm_cell_bwd: workspace %zu < %zu bytes", workspace_bytes, s.total);
     hipStream_t st = (hipStream_t)stream;
@@ -466,26 +484,26 @@ extern "C" int plc_convlstm_cell_bwd(const float* x, const float* h, const float
     const long long hw = (long long)H * W;
     int rc;
     // recompute the forward to obtain the gate activations
-    if ((rc = plc_nchw_f32_to_cb8_bf16(x, ws + s.f.x, B, Cin, H, W, stream))) return rc;
-    if ((rc = plc_nchw_f32_to_cb8_bf16(h, ws + s.f.h, B, Ch, H, W, stream))) return rc;
-    if ((rc = plc_nchw_f32_to_cb8_f32(c, (float*)(ws + s.f.c), B, Ch, H, W, stream))) return rc;
-    if ((rc = plc_pack_conv_weight(weight, bias, ws + s.f.wpk, (float*)(ws + s.f.bpk), 4 * Ch, Cin, Ch, 3,
+    if ((rc = plc_nchw_f32_to_cb8_bf16(x, ws + s.f.x, B, Cin_r, H, W, stream))) return rc;
+    if ((rc = plc_nchw_f32_to_cb8_bf16(h, ws + s.f.h, B, Ch_r, H, W, stream))) return rc;
+    if ((rc = plc_nchw_f32_to_cb8_f32(c, (float*)(ws + s.f.c), B, Ch_r, H, W, stream))) return rc;
+    if ((rc = plc_pack_conv_weight(weight, bias, ws + s.f.wpk, (float*)(ws + s.f.bpk), 4 * Ch_r, Cin_r, Ch_r, 3,
                                    PLC_PACK_LSTM, stream)))
         return rc;
     if ((rc = cell_fwd_cb8(ws + s.f.x, ws + s.f.h, (float*)(ws + s.f.c), ws + s.f.wpk, (float*)(ws + s.f.bpk),
                            ws + s.f.ho, (float*)(ws + s.f.co), ws + s.gates, B, Cin, Ch, H, W, st)))
         return rc;
     // pointwise backward
-    if ((rc = plc_nchw_f32_to_cb8_bf16(dh_next, ws + s.dh8, B, Ch, H, W, stream))) return rc;
+    if ((rc = plc_nchw_f32_to_cb8_bf16(dh_next, ws + s.dh8, B, Ch_r, H, W, stream))) return rc;
     float* dc_in = (float*)(ws + s.dc);
     float* dc_out = (float*)(ws + s.dc + (size_t)B * (Ch / 8) * hw * 32);
-    if ((rc = plc_nchw_f32_to_cb8_f32(dc_next, dc_in, B, Ch, H, W, stream))) return rc;
+    if ((rc = plc_nchw_f32_to_cb8_f32(dc_next, dc_in, B, Ch_r, H, W, stream))) return rc;
     if ((rc = lstm_pointwise_bwd(view(ws + s.dh8, (Ch / 8) * hw * 16), view(nullptr, 0), view(nullptr, 0), dc_in,
                                  ws + s.gates, ws + s.f.c, ws + s.f.co, ws + s.dz, dc_out, B, Ch, H, W, st)))
         return rc;
     // data gradient
-    if ((rc = pack_conv_weight_T(weight, ws + s.wpkT, (float*)(ws + s.bpk0), 4 * Ch, Cin, Ch, 3,
-                                 cell_dgrad_ksplit(Cin, Ch), st, !cell_fast(Cin, Ch))))
+    if ((rc = pack_conv_weight_T(weight, ws + s.wpkT, (float*)(ws + s.bpk0), 4 * Ch_r, Cin_r, Ch_r, 3,
+                                 cell_dgrad_ksplit(Cin, Ch), st, !cell_fast(Cin, Ch), Ch_r)))
         return rc;
     if ((rc = cell_dgrad(ws + s.dz, ws + s.wpkT, (const float*)(ws + s.bpk0), ws + s.dcat, B, Cin, Ch, H, W, st)))
         return rc;
@@ -493,7 +511,7 @@ extern "C" int plc_convlstm_cell_bwd(const float* x, const float* h, const float
     SlabArena arena;
     arena_begin(&arena, ws + s.slab, cell_wgrad_slab_bytes(Cin, Ch));
     if ((rc = cell_wgrad(ws + s.dz, tens(ws + s.f.x, (Cin / 8) * hw * 16, 0), tens(ws + s.f.h, (Ch / 8) * hw * 16, 0),
-                         B, B, &arena, dweight, dbias, Cin, Ch, H, W, st)))
+                         B, B, &arena, dweight, dbias, Cin, Ch, H, W, st, false, Cin_r, Ch_r)))
         return rc;
     if ((rc = arena_flush(&arena, st))) return rc;
     // back to the boundary layout: dcat = [dx (Cin) | dh (Ch)] per image
@@ -501,14 +519,14 @@ extern "C" int plc_convlstm_cell_bwd(const float* x, const float* h, const float
         const long long cat_img = ((Cin + Ch) / 8) * hw * 16;
         // dx / dh are strided views of dcat: convert image by image through the generic kernel
         for (int b = 0; b < B; ++b) {
-            if ((rc = plc_cb8_bf16_to_nchw_f32(ws + s.dcat + b * cat_img, dx + (long long)b * Cin * hw, 1, Cin, H, W, stream)))
+            if ((rc = plc_cb8_bf16_to_nchw_f32(ws + s.dcat + b * cat_img, dx + (long long)b * Cin_r * hw, 1, Cin_r, H, W, stream)))
                 return rc;
-            if ((rc = plc_cb8_bf16_to_nchw_f32(ws + s.dcat + b * cat_img + (Cin / 8) * hw * 16, dh + (long long)b * Ch * hw,
-                                               1, Ch, H, W, stream)))
+            if ((rc = plc_cb8_bf16_to_nchw_f32(ws + s.dcat + b * cat_img + (Cin / 8) * hw * 16, dh + (long long)b * Ch_r * hw,
+                                               1, Ch_r, H, W, stream)))
                 return rc;
         }
     }
-    if ((rc = plc_cb8_f32_to_nchw_f32(dc_out, dc, B, Ch, H, W, stream))) return rc;
+    if ((rc = plc_cb8_f32_to_nchw_f32(dc_out, dc, B, Ch_r, H, W, stream))) return rc;
     return PLC_OK;
 }
 
@@ -532,7 +550,7 @@ static size_t bwd_zero_bias_floats(int C1, int C2) {
 }
 
 static int bwd_plan(const plc_rollout_desc* d, const RolloutPlan& fp, BwdPlan* p) {
-    const int C1 = d->C1, C2 = d->C2, B = d->B, T = d->T, NI = d->B * d->T;
+    const int C1 = pad8(d->C1), C2 = pad8(d->C2), R2 = d->C2, B = d->B, T = d->T, NI = d->B * d->T;   // (whole-block widths)
     const size_t hw = (size_t)d->H * d->W, ohw = (size_t)d->out_H * d->out_W;
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t at = o; o += align256(bytes); return at; };
@@ -545,8 +563,8 @@ static int bwd_plan(const plc_rollout_desc* d, const RolloutPlan& fp, BwdPlan* p
     p->post0T = take(packedT_weight_bytes(32, C2, 0, 3, 1));
     p->cell1T = take(packedT_weight_bytes(4 * C1, C1, C1, 3, 1));
     p->cell2T = take(packedT_weight_bytes(4 * C2, C1, C2, 3, 2));
-    p->lu2T = take(packedT_weight_bytes(C2, C2 / 2, 0, 1, 1));
-    p->dem2T = take(packedT_weight_bytes(C2, C2 / 2, 0, 1, 1));
+    p->lu2T = take(packedT_weight_bytes(C2, R2 / 2, 0, 1, 1));
+    p->dem2T = take(packedT_weight_bytes(C2, R2 / 2, 0, 1, 1));
     for (int k = 0; k < d->n_blocks; ++k) p->upT[k] = take(packedT_weight_bytes(4 * C2, C2, 0, 3, 2));
     p->bpk0 = take(bwd_zero_bias_floats(C1, C2) * sizeof(float));
     p->d_pre0 = take((size_t)NI * 4 * ohw * 16);
@@ -554,8 +572,8 @@ static int bwd_plan(const plc_rollout_desc* d, const RolloutPlan& fp, BwdPlan* p
     p->d_pre = take((size_t)NI * (C2 / 8) * ohw * 16);
     p->d_lu_pre = take((size_t)B * (C2 / 8) * ohw * 16);
     p->d_dem_pre = take((size_t)B * (C2 / 8) * ohw * 16);
-    p->d_lu_mid = take((size_t)B * cdiv(C2 / 2, 8) * ohw * 16);
-    p->d_dem_mid = take((size_t)B * cdiv(C2 / 2, 8) * ohw * 16);
+    p->d_lu_mid = take((size_t)B * cdiv(R2 / 2, 8) * ohw * 16);
+    p->d_dem_mid = take((size_t)B * cdiv(R2 / 2, 8) * ohw * 16);
     for (int k = 0; k < d->n_blocks; ++k) {
         const size_t s = (size_t)(d->H << k) * (d->W << k);
         p->d_conv[k] = take((size_t)NI * (4 * C2 / 8) * s * 16);
@@ -618,7 +636,9 @@ extern "C" int plc_generator_rollout_bwd(const plc_rollout_desc* d, const plc_ro
     ForkGuard forks(st);              // joins the auxiliary streams on an early (error) return too
     char* wf = (char*)d->workspace;   // forward workspace: saved activations
     char* wb = (char*)g->workspace;   // backward scratch
-    const int B = d->B, T = d->T, H = d->H, W = d->W, C1 = d->C1, C2 = d->C2, L = d->L, NI = B * T;
+    // C1, C2: the widths as whole 8-channel blocks (every buffer and kernel); R1, R2: the model's own (packers and
+    // the slab reduction, which leave the padding rows and columns out)
+    const int B = d->B, T = d->T, H = d->H, W = d->W, C1 = pad8(d->C1), C2 = pad8(d->C2), R1 = d->C1, R2 = d->C2, L = d->L, NI = B * T;
     const int oH = d->out_H, oW = d->out_W;
     const long long hw = (long long)H * W, ohw = (long long)oH * oW;
     SlabArena arena;
@@ -629,13 +649,13 @@ extern "C" int plc_generator_rollout_bwd(const plc_rollout_desc* d, const plc_ro
     // the attention branches' whole backward go to the side stream and run beside the data-gradient chain and the
     // BPTT loop.  side_aux != nullptr: that is the case.
     PlcAux* side_aux = nullptr;
-    if (widths_fast(d->C1, d->C2) && plc_use_side_stream((long long)d->B * d->out_H * d->out_W)) {
+    if (widths_fast(C1, C2) && plc_use_side_stream((long long)d->B * d->out_H * d->out_W)) {
         if ((rc = plc_aux(&side_aux))) return rc;
         arena.no_early_flush = true;
     }
     hipStream_t const ss = side_aux ? side_aux->side : (hipStream_t)stream;       // the leaves' stream
     const float* bpk0 = (const float*)(wb + bp.bpk0);
-    const int mcb = cdiv(C2 / 2, 8);
+    const int mcb = cdiv(R2 / 2, 8);
     const long long fimg = (C2 / 8) * ohw * 16;   // one C2-channel image at output resolution
 
     hipLaunchKernelGGL(plc_zero_words_kernel, dim3(1), dim3(256), 0, st, (unsigned*)(wb + bp.bpk0),
@@ -647,17 +667,19 @@ extern "C" int plc_generator_rollout_bwd(const plc_rollout_desc* d, const plc_ro
     {
         PackBatch batch;
         pack_batch_begin(&batch);
-        auto packT = [&](const float* w, size_t at, int cout, int c0, int c1, int ks, int ksplit, int g) {
-            return pack_batch_add(&batch, pack_job_T(w, wb + at, nullptr, cout, c0, c1, ks, ksplit, g), st);
+        auto packT = [&](const float* w, size_t at, int cout, int c0, int c1, int ks, int ksplit, int g, int lstm_k = 0,
+                         int k_blocks = 0) {
+            return pack_batch_add(&batch, pack_job_T(w, wb + at, nullptr, cout, c0, c1, ks, ksplit, g, lstm_k, k_blocks), st);
         };
         if ((rc = packT(d->post2_w, bp.post2T, 1, 32, 0, 3, 1, 0))) return rc;
-        if ((rc = packT(d->post0_w, bp.post0T, 32, C2, 0, 3, 1, 0))) return rc;
-        if ((rc = packT(d->cell1_w, bp.cell1T, 4 * C1, C1, C1, 3, cell_dgrad_ksplit(C1, C1), !cell_fast(C1, C1)))) return rc;
-        if ((rc = packT(d->cell2_w, bp.cell2T, 4 * C2, C1, C2, 3, cell_dgrad_ksplit(C1, C2), !cell_fast(C1, C2)))) return rc;
-        if ((rc = packT(d->lu2_w, bp.lu2T, C2, C2 / 2, 0, 1, 1, gen))) return rc;
-        if ((rc = packT(d->dem2_w, bp.dem2T, C2, C2 / 2, 0, 1, 1, gen))) return rc;
+        if ((rc = packT(d->post0_w, bp.post0T, 32, R2, 0, 3, 1, 0))) return rc;
+        if ((rc = packT(d->cell1_w, bp.cell1T, 4 * R1, R1, R1, 3, cell_dgrad_ksplit(C1, C1), !cell_fast(C1, C1), R1))) return rc;
+        if ((rc = packT(d->cell2_w, bp.cell2T, 4 * R2, R1, R2, 3, cell_dgrad_ksplit(C1, C2), !cell_fast(C1, C2), R2))) return rc;
+        if ((rc = packT(d->lu2_w, bp.lu2T, R2, R2 / 2, 0, 1, 1, gen))) return rc;
+        if ((rc = packT(d->dem2_w, bp.dem2T, R2, R2 / 2, 0, 1, 1, gen))) return rc;
+        // (the gradient before the pixel shuffle holds 4 * C2 channels, those past 4 * R2 zero)
         for (int k = 0; k < d->n_blocks; ++k)
-            if ((rc = packT(d->up_w[k], bp.upT[k], 4 * C2, C2, 0, 3, 2, gen))) return rc;
+            if ((rc = packT(d->up_w[k], bp.upT[k], 4 * R2, R2, 0, 3, 2, gen, 0, 4 * C2 / 8))) return rc;
         if ((rc = pack_batch_flush(&batch, st))) return rc;
     }
     if (side_aux) {
@@ -694,8 +716,8 @@ extern "C" int plc_generator_rollout_bwd(const plc_rollout_desc* d, const plc_ro
         in.src0 = tens(wf + fp.fin, fimg, (long long)B * fimg);
         in.gate = tens(wf + fp.gate, fimg, 0);
         if ((rc = fast ? launch_wgrad<4, 0, 1, 3, STAGE_CB8_GATED>(in, tens(wb + bp.d_pre0, 4 * ohw * 16, (long long)B * 4 * ohw * 16),
-                                                                   4, NI, slab, g->post0_w, g->post0_b, 32, C2, 0, ss)
-                       : wgrad_chunked<4, 1, 3, STAGE_CB8_GATED>(in, C2, 0, tens(wb + bp.d_pre0, 4 * ohw * 16, (long long)B * 4 * ohw * 16),
+                                                                   4, NI, slab, g->post0_w, g->post0_b, 32, R2, 0, ss)
+                       : wgrad_chunked<4, 1, 3, STAGE_CB8_GATED>(in, R2, 0, tens(wb + bp.d_pre0, 4 * ohw * 16, (long long)B * 4 * ohw * 16),
                                                                  32, NI, slab, g->post0_w, g->post0_b, ss)))
             return rc;
         a = conv_args(oH, oW, B);
@@ -748,8 +770,8 @@ extern "C" int plc_generator_rollout_bwd(const plc_rollout_desc* d, const plc_ro
             ConvArgs in = conv_args(oH, oW, B);
             in.src0 = tens(wf + q.mid, mcb * ohw * 16, 0);
             if ((rc = fast ? launch_wgrad<2, 0, 1, 1, STAGE_CB8>(in, tens(wb + q.d_pre, fimg, 0), C2 / 8, B, slab,
-                                                                 q.g2w, q.g2b, C2, C2 / 2, 0, st)
-                           : wgrad_chunked<4, 4, 1, STAGE_CB8>(in, C2 / 2, 0, tens(wb + q.d_pre, fimg, 0), C2, B, slab,
+                                                                 q.g2w, q.g2b, R2, R2 / 2, 0, st)
+                           : wgrad_chunked<4, 4, 1, STAGE_CB8>(in, R2 / 2, 0, tens(wb + q.d_pre, fimg, 0), R2, B, slab,
                                                                q.g2w, q.g2b, st)))
                 return rc;
             ConvArgs a = conv_args(oH, oW, B);
@@ -761,17 +783,17 @@ extern "C" int plc_generator_rollout_bwd(const plc_rollout_desc* d, const plc_ro
             a.bpk = bpk0;
             a.ncb_out = mcb;
             if ((rc = fast ? launch_conv<4, 0, 1, 1, STAGE_CB8, EPI_ACT_CB8>(a, B, 1, st)
-                           : launch_convg<1, STAGE_CB8, EPI_ACT_CB8>(a, C2 / 8, 0, cdiv(C2 / 2, 32), B, st)))
+                           : launch_convg<1, STAGE_CB8, EPI_ACT_CB8>(a, C2 / 8, 0, cdiv(R2 / 2, 32), B, st)))
                 return rc;
             // 3x3 conv (aux -> C2/2): weight gradient only (the aux maps need no gradient)
             in = conv_args(oH, oW, B);
             in.src0 = tens(wf + q.hr, cdiv(q.cin, 8) * ohw * 16, 0);
             // (more than 32 mid channels: one launch per 32-row group of dz)
             if (q.cin <= 8)
-                rc = wgrad_chunked<1, 1, 3, STAGE_CB8>(in, q.cin, 0, tens(wb + q.d_mid, mcb * ohw * 16, 0), C2 / 2, B, slab,
+                rc = wgrad_chunked<1, 1, 3, STAGE_CB8>(in, q.cin, 0, tens(wb + q.d_mid, mcb * ohw * 16, 0), R2 / 2, B, slab,
                                                        q.g0w, q.g0b, st);
             else
-                rc = wgrad_chunked<2, 1, 3, STAGE_CB8>(in, q.cin, 0, tens(wb + q.d_mid, mcb * ohw * 16, 0), C2 / 2, B, slab,
+                rc = wgrad_chunked<2, 1, 3, STAGE_CB8>(in, q.cin, 0, tens(wb + q.d_mid, mcb * ohw * 16, 0), R2 / 2, B, slab,
                                                        q.g0w, q.g0b, st);
             if (rc) return rc;
         }
@@ -809,8 +831,8 @@ extern "C" int plc_generator_rollout_bwd(const plc_rollout_desc* d, const plc_ro
         ConvArgs in = conv_args(kh, kw, NI);
         in.src0 = tens(in_k, (C2 / 8) * khw * 16, 0);
         if ((rc = fast ? launch_wgrad<4, 0, 4, 3, STAGE_CB8>(in, tens(wb + bp.d_conv[k], (4 * C2 / 8) * khw * 16, 0), 4 * C2 / 8,
-                                                             NI, slab, g->up_w[k], g->up_b[k], 4 * C2, C2, 0, ss)
-                       : wgrad_chunked<4, 4, 3, STAGE_CB8>(in, C2, 0, tens(wb + bp.d_conv[k], (4 * C2 / 8) * khw * 16, 0), 4 * C2,
+                                                             NI, slab, g->up_w[k], g->up_b[k], 4 * R2, R2, 0, ss)
+                       : wgrad_chunked<4, 4, 3, STAGE_CB8>(in, R2, 0, tens(wb + bp.d_conv[k], (4 * C2 / 8) * khw * 16, 0), 4 * R2,
                                                            NI, slab, g->up_w[k], g->up_b[k], ss)))
             return rc;
         ConvArgs a = conv_args(kh, kw, NI);
@@ -979,18 +1001,18 @@ extern "C" int plc_generator_rollout_bwd(const plc_rollout_desc* d, const plc_ro
         in.row_tab = d->row_tab;
         in.col_tab = d->col_tab;
         const PlcTensor relu_of = tens(wf + fp.xs, fp.img1, (long long)B * fp.img1);      // stem output
-        if ((rc = wgrad_chunked<1, 1, 3, STAGE_COORD>(in, 3, 0, tens(wb + bp.dcat1, cat1, (long long)B * cat1), C1, NI,
+        if ((rc = wgrad_chunked<1, 1, 3, STAGE_COORD>(in, 3, 0, tens(wb + bp.dcat1, cat1, (long long)B * cat1), R1, NI,
                                                       slab, g->init_w, g->init_b, sw, &relu_of)))
             return rc;
     }
     // ---- gate-conv weight gradients, batched over all T*B frames -------------------------------
     if ((rc = cell_wgrad(wb + bp.dz2, tens(wf + fp.h1s + s1, fp.img1, (long long)B * fp.img1),
                          tens(wf + fp.h2s, fp.img2, (long long)B * fp.img2), B, NI, slab, g->cell2_w,
-                         g->cell2_b, C1, C2, H, W, st, true)))
+                         g->cell2_b, C1, C2, H, W, st, true, R1, R2)))
         return rc;
     if ((rc = cell_wgrad(wb + bp.dz1, tens(wf + fp.xs, fp.img1, (long long)B * fp.img1),
                          tens(wf + fp.h1s, fp.img1, (long long)B * fp.img1), B, NI, slab, g->cell1_w,
-                         g->cell1_b, C1, C1, H, W, sw, true)))
+                         g->cell1_b, C1, C1, H, W, sw, true, R1, R1)))
         return rc;
     // ---- every conv's slabs -> parameter gradients, one launch ----------------------------------
     if (side_aux) {                      // join: every leaf has written its slabs

@@ -7,7 +7,8 @@ enum { PACK_PLAIN = 0, PACK_LSTM = 1, PACK_PIXSHUF = 2 };
 // Output-channel index of row r (0..31) of M tile mt.  Row r = 8g + j8 (see plc_conv_kernel.h).
 __device__ __forceinline__ int plc_row_to_cout(int mode, int mt, int r, int ch_per_gate) {
     const int g = r >> 3, j8 = r & 7;
-    if (mode == PACK_LSTM) return g * ch_per_gate + 8 * mt + j8;        // gate-major conv channels
+    // gate-major conv channels; hidden channels past ch_per_gate (a width that is not a multiple of 8) are padding
+    if (mode == PACK_LSTM) return 8 * mt + j8 < ch_per_gate ? g * ch_per_gate + 8 * mt + j8 : (1 << 30);
     if (mode == PACK_PIXSHUF) return 4 * (8 * mt + j8) + g;             // PixelShuffle(2): 4c + 2i + j
     return 32 * mt + r;
 }
@@ -40,6 +41,10 @@ struct PackJob {
     float* bpk;
     int cout, c0, c1, ks, mode, n_mt, nks_w, ch_per_gate, transposed, ksplit;
     int chunk;
+    int lstm_k;                     // transposed jobs: > 0 = the K channels are an LSTM gate conv's outputs as the engine
+                                    // stores them (gate-major, each gate padded to whole 8-channel blocks) and this many
+                                    // hidden channels are real; 0 = plain channel order
+    int k_blocks;                   // transposed jobs: 8-channel blocks of the K axis (>= ceil(cout / 8); the rest are zero)
     int first_block, n_blocks;      // position inside a multi-job launch
 };
 
@@ -50,7 +55,8 @@ __device__ __forceinline__ void plc_pack_weight_body(const PackJob& jb, int bloc
     float* __restrict__ bpk = jb.bpk;
     const int cout = jb.cout, c0 = jb.c0, c1 = jb.c1, ks = jb.ks, mode = jb.mode, n_mt = jb.n_mt, nks_w = jb.nks_w;
     const int ch_per_gate = jb.ch_per_gate, transposed = jb.transposed, ksplit = jb.ksplit;
-    const int ncb_k = transposed ? (cout + 7) / 8 : (c0 + 7) / 8 + (c1 + 7) / 8;
+    const int lstm_nmt = (jb.lstm_k + 7) / 8;
+    const int ncb_k = transposed ? jb.k_blocks : (c0 + 7) / 8 + (c1 + 7) / 8;
     const int ncbw = ncb_k / ksplit;
     const int taps = ks * ks;
     const long long total = (long long)n_mt * ksplit * nks_w * 64 * 8;
@@ -88,7 +94,11 @@ __device__ __forceinline__ void plc_pack_weight_body(const PackJob& jb, int bloc
             } else {
                 const int rowg = 32 * mt + r;
                 const int ci = plc_padded_to_concat(rowg >> 3, rowg & 7, c0, c1);
-                const int o = 8 * cb + j;
+                int o = 8 * cb + j;
+                if (jb.lstm_k > 0) {            // block cb = gate g, hidden channels 8 * (cb % lstm_nmt) ..
+                    const int hc = 8 * (cb % lstm_nmt) + j;
+                    o = hc < jb.lstm_k ? (cb / lstm_nmt) * jb.lstm_k + hc : (1 << 30);
+                }
                 if (o < cout && ci >= 0 && (rowg >> 3) < (c0 + 7) / 8 + (c1 + 7) / 8)
                     v = w[(((long long)o * (c0 + c1) + ci) * ks + (ks - 1 - dy)) * ks + (ks - 1 - dx)];
             }
@@ -172,21 +182,24 @@ __global__ void plc_cb8_to_nchw_kernel(const uint4* __restrict__ src, float* __r
     }
 }
 
-// NCHW fp32 <-> CB8 fp32 (cell state); dir 0: NCHW -> CB8, dir 1: CB8 -> NCHW.  C % 8 == 0.
+// NCHW fp32 <-> CB8 fp32 (cell state); dir 0: NCHW -> CB8 (channels padded with zeros to a multiple of 8),
+// dir 1: CB8 -> NCHW.
 __global__ void plc_state_layout_kernel(const float* __restrict__ src, float* __restrict__ dst,
                                         int N, int C, int H, int W, int dir) {
     const long long hw = (long long)H * W;
-    const long long total = (long long)N * C * hw;
+    const int ncb = (C + 7) / 8;
+    const long long total = (long long)N * ncb * 8 * hw;
     for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
          idx += (long long)gridDim.x * blockDim.x) {
         // idx enumerates the CB8 side: [n][cb][pix][j]
         const int j = idx & 7;
         const long long pix = (idx >> 3) % hw;
-        const int cb = ((idx >> 3) / hw) % (C / 8);
-        const long long n = (idx >> 3) / (hw * (C / 8));
+        const int cb = ((idx >> 3) / hw) % ncb;
+        const long long n = (idx >> 3) / (hw * ncb);
+        const bool real = 8 * cb + j < C;
         const long long nchw = (n * C + 8 * cb + j) * hw + pix;
-        if (dir == 0) dst[idx] = src[nchw];
-        else dst[nchw] = src[idx];
+        if (dir == 0) dst[idx] = real ? src[nchw] : 0.0f;
+        else if (real) dst[nchw] = src[idx];
     }
 }
 

@@ -436,6 +436,9 @@ struct FinalizeJob {
     float* db;
     int n_slabs, rows_pad, cols_pad, cout, c0, c1, ks, ncb;
     int ci_off, c_total;            // the job's input channels are channels ci_off.. of a conv with c_total of them
+    int row_off, cout_total;        // slab row r is row row_off + r of the conv's dz channels; the conv has cout_total outputs
+    int lstm_ch;                    // > 0: the dz channels are an LSTM gate conv's outputs as the engine stores them
+                                    // (gate-major, each gate padded to whole 8-channel blocks), lstm_ch hidden channels real
     int first_block, n_blocks;      // position inside a multi-job launch
 };
 
@@ -474,9 +477,16 @@ __device__ __forceinline__ void plc_wgrad_finalize_body(const FinalizeJob& jb, i
             float t = part[0][el];
 #pragma unroll
             for (int k = 1; k < 8; ++k) t += part[k][el];
-            const int o = idx / cols_pad, ncol = idx % cols_pad;
+            const int ncol = idx % cols_pad;
+            int o = jb.row_off + (int)(idx / cols_pad);              // position among the dz channels
+            if (jb.lstm_ch > 0) {
+                const int chp = (jb.lstm_ch + 7) & ~7, hc = o % chp;
+                o = hc < jb.lstm_ch ? (o / chp) * jb.lstm_ch + hc : jb.cout_total;
+            }
             const int grp = ncol >> 4, c16 = ncol & 15;
-            if (grp < taps * ncbp) {
+            if (o >= jb.cout_total) {
+                // a padding row: no such output channel
+            } else if (grp < taps * ncbp) {
                 const int tap = grp / ncbp;
                 const int cb = 2 * (grp % ncbp) + (c16 >> 3);
                 const int ci = cb < ncb ? plc_padded_to_concat(cb, c16 & 7, c0, c1) : -1;

@@ -18,8 +18,8 @@ Files
   step_s2.npz         one optimisation step in trainer.py:290-315 order, Adam built before the
                       first forward as trainer.py:153-158 does (lazy blocks are not updated)
   genw_*.npz          Generator of other widths (the class default hidden_dims=[32,64] of
-                      generator.py:33, and [8,24]) with its own parameters ("param.<key>"), forward
-                      and parameter gradients
+                      generator.py:33, [8,24], and [10,20] / [12,30], which are no multiples of 8) with its
+                      own parameters ("param.<key>"), forward and parameter gradients
 """
 import os
 import sys
@@ -269,4 +269,9 @@ wide_case("genw_default_s2.npz", None, 1, 2, 8, 8, 51, dict(scale_factor=2),
                       "dem_attn.conv.0", "lu_attn.conv.0", "lu_attn.conv.2.bias", "upsample_blocks.0.conv.bias"))
 # widths that are no multiple of 16: three hidden channel blocks, odd chunk sizes
 wide_case("genw_8_24_s1.npz", [8, 24], 2, 3, 12, 9, 52, dict(scale_factor=1), with_grads="all")
+# widths that are no multiple of 8 (the reference takes any, generator.py:32-58): the engine carries them as the
+# next multiple with zero channels.  [10, 20] through an upsample block (run-time-width kernels), [12, 30] at
+# scale 1 (carried as [16, 32]: the instantiated kernels)
+wide_case("genw_10_20_s2.npz", [10, 20], 2, 3, 9, 12, 53, dict(scale_factor=2), with_grads="all")
+wide_case("genw_12_30_s1.npz", [12, 30], 2, 3, 12, 9, 54, dict(scale_factor=1), with_grads="all")
 print("done")

@@ -29,7 +29,10 @@ def build(gpu, hidden, s, params):
     return m.to(gpu)
 
 
-@pytest.mark.parametrize("name,hidden,s", [("genw_default_s2.npz", [32, 64], 2), ("genw_8_24_s1.npz", [8, 24], 1)])
+@pytest.mark.parametrize("name,hidden,s", [("genw_default_s2.npz", [32, 64], 2), ("genw_8_24_s1.npz", [8, 24], 1),
+                                           # widths that are no multiples of 8 (the engine carries them as the next
+                                           # multiple with zero channels): run-time-width kernels / instantiated kernels
+                                           ("genw_10_20_s2.npz", [10, 20], 2), ("genw_12_30_s1.npz", [12, 30], 1)])
 def test_other_widths_vs_reference_golden(gpu, name, hidden, s):
     from pl_convlstm_gan_amd.losses import CombinedLoss
     g = load_golden(name)
@@ -63,6 +66,10 @@ WIDTH_CASES = [
     ([24, 40], 1, 3, 20, 36, 2, 9),      # odd block counts (3 and 5), two land-use blocks
     ([64, 128], 1, 2, 12, 40, 1, 5),     # more input blocks than one LDS chunk holds, 16 output tiles
     ([16, 64], 1, 2, 16, 16, 1, 5),      # instantiated cell 1 beside a run-time-width cell 2
+    ([10, 20], 2, 3, 21, 40, 1, 5),      # no multiples of 8: carried as [16, 24] with zero channels
+    ([13, 27], 1, 3, 20, 36, 4, 3),      # ... carried as [16, 32] (the instantiated kernels), two upsample blocks
+    ([3, 5], 2, 2, 17, 33, 2, 2),        # narrower than one block (5 // 2 = 2 channels inside the attention branches)
+    ([16, 35], 1, 2, 12, 40, 1, 5),      # an odd second width: 17 attention mid channels (three blocks)
 ]
 
 
@@ -91,7 +98,7 @@ def test_other_widths_forward_and_grads_vs_oracle(gpu, case):
         assert emax <= 3e-2 and el2 <= 3e-2, (k, emax, el2)
 
 
-@pytest.mark.parametrize("cin,ch", [(32, 32), (32, 64), (8, 24)])
+@pytest.mark.parametrize("cin,ch", [(32, 32), (32, 64), (8, 24), (10, 20), (12, 30), (5, 3)])
 def test_cell_other_widths(gpu, cin, ch):
     """ConvLSTMCell.forward and its gradients at other widths against the oracle."""
     from pl_convlstm_gan_amd import ConvLSTMCell

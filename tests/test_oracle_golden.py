@@ -142,7 +142,8 @@ def test_train_step_order():
         assert float((expect - after)[mask].abs().max()) <= 2e-5, key
 
 
-WIDE_CASES = {"genw_default_s2.npz": ([32, 64], 2), "genw_8_24_s1.npz": ([8, 24], 1)}
+WIDE_CASES = {"genw_default_s2.npz": ([32, 64], 2), "genw_8_24_s1.npz": ([8, 24], 1),
+              "genw_10_20_s2.npz": ([10, 20], 2), "genw_12_30_s1.npz": ([12, 30], 1)}
 
 
 def wide_params(g):
