@@ -13,6 +13,7 @@
 #include "plc_conv_kernel.h"
 #include "plc_convg_kernel.h"
 #include "plc_convr_kernel.h"
+#include "plc_post_kernel.h"
 #include "plc_misc_kernels.h"
 #include "plc_fp8_kernels.h"
 
@@ -410,6 +411,12 @@ static int launch_conv(ConvArgs a, int n_img, int n_mgroups, hipStream_t st) {
 static bool plc_use_side_stream(long long out_px) {
     static const bool off = [] { const char* e = getenv("PLC_NO_SIDE_STREAM"); return e && *e && *e != '0'; }();
     return !off && out_px >= (1ll << 17);
+}
+
+// PLC_NO_POST_FUSION=1 keeps the generator's two output convs in launches of their own (results are bit-identical).
+static bool plc_no_post_fusion() {
+    static const bool off = [] { const char* e = getenv("PLC_NO_POST_FUSION"); return e && *e && *e != '0'; }();
+    return off;
 }
 
 // Debugging / measurement switch: PLC_NO_ROLLING=1 keeps the tile-at-a-time kernels where a rolling-window
@@ -1308,6 +1315,37 @@ extern "C" int plc_generator_rollout_fwd(const plc_rollout_desc* d, void* stream
     if (side_aux) {
         PLC_HIP(hipStreamWaitEvent(st, side_aux->sev[1], 0));           // the gate maps are ready
         forks.joined(side_aux->side);
+    }
+    if (C2 == 32 && !plc_no_post_fusion()) {
+        // both output convs in one kernel (plc_post_kernel.h): the 32-channel intermediate stays in LDS; a training
+        // forward also stores it for the backward pass.  Bit-identical to the two launches below.
+        PostArgs a;
+        memset(&a, 0, sizeof(a));
+        a.H = oH; a.W = oW; a.n_in = B;
+        a.tiles_x = cdiv(oW, POST_TW);
+        a.tiles_y = cdiv(oH, POST_TH);
+        const long long tiles = (long long)NI * a.tiles_x * a.tiles_y;
+        if (tiles >= (1ll << 31)) return plc_fail(PLC_EINVAL, "rollout: bad tile count");
+        a.n_tiles = (int)tiles;
+        a.feat = tens(feat, (C2 / 8) * ohw * 16, (long long)B * (C2 / 8) * ohw * 16);
+        a.gate = tens(ws + p.gate, (C2 / 8) * ohw * 16, 0);
+        a.p0 = tens(ws + p.p0, 4 * ohw * 16, (long long)B * 4 * ohw * 16);
+        a.out = tens(d->out, (long long)T * ohw * 4, ohw * 4);      // n = t*B + b  ->  out[b][t]
+        a.wpk0 = (const uint4*)(ws + p.post0.w);
+        a.bpk0 = (const float*)(ws + p.post0.b);
+        a.wpk2 = (const uint4*)(ws + p.post2.w);
+        a.bpk2 = (const float*)(ws + p.post2.b);
+        const bool save = d->save_for_backward != 0;
+        auto kern = save ? plc_post_fused_kernel<true> : plc_post_fused_kernel<false>;
+        static bool lds_raised[2][64] = {{false}};
+        if ((rc = ensure_lds_limit((const void*)kern, POST_LDS_BYTES, lds_raised[save ? 1 : 0]))) return rc;
+        // one workgroup per CU: two groups of four waves, each with its own tile buffers, taking turns
+        const int resident = cu_count();
+        const int want = (a.n_tiles + 1) / 2;                       // (at least two tiles per workgroup)
+        const int grid = want < resident ? (want < 1 ? 1 : want) : resident;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(512), POST_LDS_BYTES, st, a);
+        PLC_HIP(hipGetLastError());
+        return PLC_OK;
     }
     {
         ConvArgs a = conv_args(oH, oW, B);

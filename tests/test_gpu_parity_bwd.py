@@ -220,8 +220,56 @@ def test_kernel_selection_switches_do_not_change_a_bit(gpu):
     branches and leaf weight gradients beside the recurrences -- to be used, at scale 1 and through three
     upsample blocks; the last two are longer rollouts at the 2^17-pixel threshold, with two chains and, for
     the single image, with one)."""
-    base = _digest_run({})
+    # (with the two output convs in launches of their own, which is what the gated conv's tile order applies to;
+    # the fused output kernel is compared with them in test_fused_output_convs_against_the_separate_launches)
+    base = _digest_run({"PLC_NO_POST_FUSION": "1"})
     assert len(base) == 8
     for env in ({"PLC_NO_ROLLING": "1"}, {"PLC_NO_PAIRING": "1"}, {"PLC_FUSED_PW": "1"}, {"PLC_NO_BWD_SPLIT": "1"},
                 {"PLC_NO_FWD_SPLIT": "1"}, {"PLC_NO_GATED_TINNER": "1"}, {"PLC_NO_SIDE_STREAM": "1"}):
-        assert _digest_run(env) == base, env
+        assert _digest_run(dict(env, PLC_NO_POST_FUSION="1")) == base, env
+
+
+def test_fused_output_convs_against_the_separate_launches(gpu, tmp_path):
+    """The generator's two output convs run as one kernel (plc_post_kernel.h); PLC_NO_POST_FUSION=1 keeps the two
+    launches.  The first conv's result -- which the backward pass reads -- is bit-identical, so for a loss that is
+    linear in the output every parameter gradient is bit-identical too; the output itself, whose one-channel conv
+    sums in another order on another matrix instruction, agrees to fp32 rounding.  Ragged sizes, tiles that
+    straddle the image border, scale 1 and through an upsample block."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, torch\n"
+        f"sys.path.insert(0, {root!r})\n"
+        "from pl_convlstm_gan_amd import Generator\n"
+        "gpu = torch.device('cuda:0')\n"
+        "res = {}\n"
+        "for i, (B, T, H, W, seed, s) in enumerate([(2, 3, 37, 45, 8, 1), (1, 2, 64, 61, 5, 1), (2, 2, 23, 17, 9, 2), (3, 2, 128, 128, 4, 1)]):\n"
+        "    torch.manual_seed(seed)\n"
+        "    m = Generator(hidden_dims=[16, 32], lu_channels=5, scale_factor=s).to(gpu)\n"
+        "    g = torch.Generator().manual_seed(seed + 1)\n"
+        "    rain = 10 * torch.rand(B, T, 1, H, W, generator=g) * (torch.rand(B, T, 1, H, W, generator=g) > 0.7)\n"
+        "    dem, lu = torch.rand(B, 1, H * s, W * s, generator=g), torch.rand(B, 5, H * s, W * s, generator=g)\n"
+        "    with torch.no_grad():\n"
+        "        inf = m(rain.to(gpu), dem.to(gpu), lu.to(gpu)).clone()\n"
+        "    out = m(rain.to(gpu), dem.to(gpu), lu.to(gpu))\n"
+        "    (out * (torch.rand(out.shape, generator=g) + 0.5).to(gpu)).sum().backward()\n"
+        "    assert torch.equal(inf, out.detach())\n"
+        "    res[f'out{i}'] = out.detach().cpu()\n"
+        "    for k, p in m.named_parameters():\n"
+        "        res[f'g{i}.{k}'] = p.grad.cpu()\n"
+        "torch.save(res, sys.argv[1])\n")
+    got = {}
+    for tag, extra in (("fused", {}), ("split", {"PLC_NO_POST_FUSION": "1"})):
+        path = str(tmp_path / f"{tag}.pt")
+        r = subprocess.run([sys.executable, "-c", code, path], env=dict(os.environ, **extra), capture_output=True, text=True, timeout=150)
+        assert r.returncode == 0, r.stderr[-2000:]
+        got[tag] = torch.load(path, weights_only=True)
+    assert set(got["fused"]) == set(got["split"])
+    for k, a in got["fused"].items():
+        b = got["split"][k]
+        if k.startswith("out"):
+            assert float((a - b).abs().max()) <= 2e-6 * float(b.abs().max()), k
+        else:
+            assert torch.equal(a, b), k
