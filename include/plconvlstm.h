@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define PLC_VERSION 101
+#define PLC_VERSION 102
 
 enum {
     PLC_OK = 0,
@@ -275,6 +275,12 @@ typedef struct plc_rollout_grads {
     /* caller-owned scratch of plc_generator_bwd_workspace_bytes(desc) bytes, 256-byte aligned */
     void* workspace;
     size_t workspace_bytes;
+    /* Optional gradients with respect to the inputs, what autograd returns for generator.py:101-205 when an input
+     * has requires_grad (fp32, device, the inputs' own shapes; overwritten).  NULL = not wanted, the case of the
+     * training step: nothing is computed for it. */
+    float* d_rain;           /* [B][T][1][H][W] */
+    float* d_dem;            /* [B][1][dem_H][dem_W] */
+    float* d_lu;             /* [B][L][lu_H][lu_W] */
 } plc_rollout_grads;
 
 size_t plc_generator_bwd_workspace_bytes(const plc_rollout_desc* d);

@@ -61,6 +61,7 @@ class RolloutGrads(C.Structure):
         ("up_w", _f * 8), ("up_b", _f * 8),
         ("post0_w", _f), ("post0_b", _f), ("post2_w", _f), ("post2_b", _f),
         ("workspace", _f), ("workspace_bytes", C.c_size_t),
+        ("d_rain", _f), ("d_dem", _f), ("d_lu", _f),
     ]
 
 

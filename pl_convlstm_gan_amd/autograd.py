@@ -83,9 +83,13 @@ class _RolloutFn(torch.autograd.Function):
             raise NotImplementedError(f"plc_generator_rollout_bwd: {msg}")
         wsb = ctx.model._bwd_workspace(nbytes, dev)
         g.workspace, g.workspace_bytes = wsb.data_ptr(), nbytes
+        # gradients of the inputs only where autograd asks for them (rain_lr, dem, lu = arguments 1..3)
+        d_in = [torch.empty_like(t, dtype=torch.float32) if ctx.needs_input_grad[1 + k] else None
+                for k, t in enumerate(ctx.keep)]
+        g.d_rain, g.d_dem, g.d_lu = (t.data_ptr() if t is not None else None for t in d_in)
         rc = L.plc_generator_rollout_bwd(C.byref(d), C.byref(g), ops._stream())
         _lib.check(rc, "plc_generator_rollout_bwd")
-        return (None, None, None, None, None) + tuple(grads)
+        return (None, d_in[0], d_in[1], d_in[2], None) + tuple(grads)
 
 
 def rollout_with_grad(model, rain_lr, dem, lu, input_grid_size, params):

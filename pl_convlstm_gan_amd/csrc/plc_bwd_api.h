@@ -535,7 +535,7 @@ extern "C" int plc_convlstm_cell_bwd(const float* x, const float* h, const float
 // ---------------------------------------------------------------------------------------------
 struct BwdPlan {
     size_t post2T, post0T, cell1T, cell2T, lu2T, dem2T, upT[8], bpk0;
-    size_t d_pre0, d_feat, d_pre, d_lu_pre, d_dem_pre, d_lu_mid, d_dem_mid;
+    size_t d_pre0, d_feat, d_pre, d_lu_pre, d_dem_pre, d_lu_mid, d_dem_mid, d_aux_hr;
     size_t d_conv[8], d_in[8];
     size_t d_mid, d_up;     // (size_t)-1 when the corresponding bilinear resize is absent
     size_t dz1, dz2, dcat1, dcat2, dc1, dc2, slab, slab_bytes, total;
@@ -574,6 +574,7 @@ static int bwd_plan(const plc_rollout_desc* d, const RolloutPlan& fp, BwdPlan* p
     p->d_dem_pre = take((size_t)B * (C2 / 8) * ohw * 16);
     p->d_lu_mid = take((size_t)B * cdiv(R2 / 2, 8) * ohw * 16);
     p->d_dem_mid = take((size_t)B * cdiv(R2 / 2, 8) * ohw * 16);
+    p->d_aux_hr = take((size_t)B * (d->L > 1 ? d->L : 1) * ohw * 4);   // fp32 input gradient of an attention branch, output grid
     for (int k = 0; k < d->n_blocks; ++k) {
         const size_t s = (size_t)(d->H << k) * (d->W << k);
         p->d_conv[k] = take((size_t)NI * (4 * C2 / 8) * s * 16);
@@ -796,6 +797,19 @@ extern "C" int plc_generator_rollout_bwd(const plc_rollout_desc* d, const plc_ro
                 rc = wgrad_chunked<2, 1, 3, STAGE_CB8>(in, q.cin, 0, tens(wb + q.d_mid, mcb * ohw * 16, 0), R2 / 2, B, slab,
                                                        q.g0w, q.g0b, st);
             if (rc) return rc;
+            // the aux map's own gradient, when asked for: through the 3x3 conv, then through the resize of
+            // generator.py:143-153 (bilinear for the DEM, nearest for land use) back to the map's own grid
+            float* const d_aux = i == 0 ? g->d_lu : g->d_dem;
+            if (d_aux) {
+                const int aH = i == 0 ? d->lu_H : d->dem_H, aW = i == 0 ? d->lu_W : d->dem_W;
+                float* const hr = (float*)(wb + bp.d_aux_hr);
+                hipLaunchKernelGGL(plc_aux_input_grad_kernel, dim3(ew_grid((long long)B * q.cin * ohw)), dim3(256), 0, st,
+                                   (const char*)(wb + q.d_mid), q.w0, hr, B, R2 / 2, q.cin, oH, oW);
+                hipLaunchKernelGGL(plc_resize_nchw_bwd_kernel, dim3(ew_grid((long long)B * q.cin * aH * aW)), dim3(256), 0,
+                                   st, (const float*)hr, d_aux, (long long)B * q.cin, aH, aW, oH, oW, i == 0 ? 1 : 0,
+                                   (float)aH / (float)oH, (float)aW / (float)oW);
+                PLC_HIP(hipGetLastError());
+            }
         }
     }
     // ---- PixelShuffle upsample blocks, last to first ------------------------------------------
@@ -1004,6 +1018,12 @@ extern "C" int plc_generator_rollout_bwd(const plc_rollout_desc* d, const plc_ro
         if ((rc = wgrad_chunked<1, 1, 3, STAGE_COORD>(in, 3, 0, tens(wb + bp.dcat1, cat1, (long long)B * cat1), R1, NI,
                                                       slab, g->init_w, g->init_b, sw, &relu_of)))
             return rc;
+        if (g->d_rain) {
+            hipLaunchKernelGGL(plc_stem_input_grad_kernel, dim3(ew_grid((long long)NI * hw)), dim3(256), 0, sw,
+                               (const char*)(wb + bp.dcat1), (long long)cat1, (const char*)(wf + fp.xs), (long long)fp.img1,
+                               d->init_w, g->d_rain, B, T, R1, H, W);
+            PLC_HIP(hipGetLastError());
+        }
     }
     // ---- gate-conv weight gradients, batched over all T*B frames -------------------------------
     if ((rc = cell_wgrad(wb + bp.dz2, tens(wf + fp.h1s + s1, fp.img1, (long long)B * fp.img1),

@@ -127,6 +127,77 @@ __global__ void plc_pixel_unshuffle_mask_kernel(const char* __restrict__ d_up, c
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Gradients with respect to the rollout's inputs (rain, DEM, land use).  Training does not ask for them (the
+// data loader's tensors need none), so these are plain one-thread-per-output kernels: small, any width, fp32
+// accumulation, and off the step's path unless an input has requires_grad.
+// ---------------------------------------------------------------------------------------------
+// Stem (generator.py:152-160: ReLU(conv3x3([rain, row, col]))): d rain[b][t][y][x] = sum over stem channels c and
+// taps of w[c][0][ky][kx] * dz[c][y - ky + 1][x - kx + 1], dz = the x-part of d[x_t | h1_{t-1}] where the stem's
+// output is positive.  dcat: CB8 bf16, image n = t*B + b at n*cat_img bytes, the stem channels first;
+// xs: the stem's output, CB8 bf16 [T*B][ncb]; w: fp32 [R1][3][3][3]; d_rain: fp32 [B][T][H][W].
+__global__ void plc_stem_input_grad_kernel(const char* __restrict__ dcat, long long cat_img, const char* __restrict__ xs,
+                                           long long xs_img, const float* __restrict__ w, float* __restrict__ d_rain,
+                                           int B, int T, int R1, int H, int W) {
+    const long long hw = (long long)H * W, total = (long long)B * T * hw;
+    const int ncb = (R1 + 7) / 8;
+    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const int x = idx % W;
+        const int y = (idx / W) % H;
+        const long long n = idx / hw;
+        const int t = n / B, b = n % B;
+        float acc = 0.0f;
+        for (int ky = 0; ky < 3; ++ky) {
+            const int yy = y - ky + 1;
+            if (yy < 0 || yy >= H) continue;
+            for (int kx = 0; kx < 3; ++kx) {
+                const int xx = x - kx + 1;
+                if (xx < 0 || xx >= W) continue;
+                for (int cb = 0; cb < ncb; ++cb) {
+                    const long long o = ((long long)cb * hw + (long long)yy * W + xx) * 16;
+                    const F8 g = ld_bf8(dcat + n * cat_img + o), a = ld_bf8(xs + n * xs_img + o);
+                    for (int j = 0; j < 8 && 8 * cb + j < R1; ++j)
+                        if (a.v[j] > 0.0f) acc = __builtin_fmaf(w[(8 * cb + j) * 27 + ky * 3 + kx], g.v[j], acc);
+                }
+            }
+        }
+        d_rain[((long long)b * T + t) * hw + (long long)y * W + x] = acc;
+    }
+}
+
+// First conv of an attention branch (attention.py:8-12: conv3x3(aux -> C/2), ReLU, conv1x1, sigmoid), data
+// gradient at the output grid: d_hr[b][c][y][x] = sum over mid channels m and taps of
+// w0[m][c][ky][kx] * d_mid[b][m][y - ky + 1][x - kx + 1]  (d_mid already carries the ReLU's mask).
+// d_mid: CB8 bf16 [B][ceil(M/8)]; w0: fp32 [M][cin][3][3]; d_hr: fp32 [B][cin][H][W].
+__global__ void plc_aux_input_grad_kernel(const char* __restrict__ d_mid, const float* __restrict__ w0,
+                                          float* __restrict__ d_hr, int B, int M, int cin, int H, int W) {
+    const long long hw = (long long)H * W, total = (long long)B * cin * hw;
+    const int mcb = (M + 7) / 8;
+    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const int x = idx % W;
+        const int y = (idx / W) % H;
+        const int c = (idx / hw) % cin;
+        const long long b = idx / (hw * cin);
+        float acc = 0.0f;
+        for (int ky = 0; ky < 3; ++ky) {
+            const int yy = y - ky + 1;
+            if (yy < 0 || yy >= H) continue;
+            for (int kx = 0; kx < 3; ++kx) {
+                const int xx = x - kx + 1;
+                if (xx < 0 || xx >= W) continue;
+                for (int cb = 0; cb < mcb; ++cb) {
+                    const F8 g = ld_bf8(d_mid + (((b * mcb + cb) * hw) + (long long)yy * W + xx) * 16);
+                    for (int j = 0; j < 8 && 8 * cb + j < M; ++j)
+                        acc = __builtin_fmaf(w0[((long long)(8 * cb + j) * cin + c) * 9 + ky * 3 + kx], g.v[j], acc);
+                }
+            }
+        }
+        d_hr[idx] = acc;
+    }
+}
+
 // Backward of plc_resize_cb8_kernel (bilinear, align_corners False), gather form: one thread per
 // SOURCE unit sums w(dst, src) * d_dst over the destination pixels whose interpolation footprint
 // contains it.  The candidate destination range comes from inverting the coordinate map, padded by
@@ -175,5 +246,61 @@ __global__ void plc_resize_cb8_bwd_kernel(const uint4* __restrict__ d_dst, uint4
             }
         }
         st_bf8((char*)(d_src + idx), acc);
+    }
+}
+
+// The same for an fp32 NCHW map, both resampling modes of plc_resize_nchw_to_cb8_kernel (mode 0: bilinear;
+// mode 1: legacy 'nearest', whose backward sums the destination pixels that read the source pixel).
+// d_dst: fp32 [planes][Ho][Wo]; d_src: fp32 [planes][Hi][Wi]; scales = in / out as in the forward.
+__global__ void plc_resize_nchw_bwd_kernel(const float* __restrict__ d_dst, float* __restrict__ d_src, long long planes,
+                                           int Hi, int Wi, int Ho, int Wo, int mode, float sh, float sw) {
+    const long long hwi = (long long)Hi * Wi, hwo = (long long)Ho * Wo;
+    const long long total = planes * hwi;
+    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const int ix = idx % Wi;
+        const int iy = (idx / Wi) % Hi;
+        const float* p = d_dst + (idx / hwi) * hwo;
+        int oy_lo, oy_hi, ox_lo, ox_hi;
+        float acc = 0.0f;
+        if (mode == 0) {
+            plc_resize_dst_range(iy, sh, Hi, Ho, oy_lo, oy_hi);
+            plc_resize_dst_range(ix, sw, Wi, Wo, ox_lo, ox_hi);
+            for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+                int y0, y1;
+                float wy;
+                plc_bilinear_coord(oy, sh, Hi, y0, y1, wy);
+                const float ky = (y0 == iy ? 1.0f - wy : 0.0f) + (y1 == iy ? wy : 0.0f);
+                if (ky == 0.0f) continue;
+                for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+                    int x0, x1;
+                    float wx;
+                    plc_bilinear_coord(ox, sw, Wi, x0, x1, wx);
+                    const float kx = (x0 == ix ? 1.0f - wx : 0.0f) + (x1 == ix ? wx : 0.0f);
+                    if (kx != 0.0f) acc = __builtin_fmaf(ky * kx, p[(long long)oy * Wo + ox], acc);
+                }
+            }
+        } else {
+            // destination d reads source min(floor(d * scale), in - 1): candidates around [i / scale, (i + 1) / scale)
+            auto range = [](int i, float scale, int in_size, int out_size, int& lo, int& hi) {
+                lo = (int)floorf((float)i / scale) - 1;
+                hi = i == in_size - 1 ? out_size - 1 : (int)ceilf((float)(i + 1) / scale) + 1;
+                lo = lo < 0 ? 0 : lo;
+                hi = hi > out_size - 1 ? out_size - 1 : hi;
+            };
+            range(iy, sh, Hi, Ho, oy_lo, oy_hi);
+            range(ix, sw, Wi, Wo, ox_lo, ox_hi);
+            for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+                int sy = (int)floorf((float)oy * sh);
+                sy = sy < Hi - 1 ? sy : Hi - 1;
+                if (sy != iy) continue;
+                for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+                    int sx = (int)floorf((float)ox * sw);
+                    sx = sx < Wi - 1 ? sx : Wi - 1;
+                    if (sx == ix) acc += p[(long long)oy * Wo + ox];
+                }
+            }
+        }
+        d_src[idx] = acc;
     }
 }

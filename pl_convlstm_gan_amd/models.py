@@ -287,10 +287,6 @@ class Generator(nn.Module):
     def forward(self, rain_lr, dem, lu, input_grid_size=None):
         """rain_lr [B,T,1,H,W], dem [B,1,Hd,Wd], lu [B,L,Hl,Wl] -> [B,T,1,Hh,Wh] (fp32)."""
         from .autograd import _param_list, rollout_with_grad
-        if torch.is_grad_enabled() and any(isinstance(t, torch.Tensor) and t.requires_grad for t in (rain_lr, dem, lu)):
-            # the reference's autograd would return these; the engine's backward pass does not form them
-            raise NotImplementedError("gradients with respect to rain_lr / dem / lu are not computed by the engine: "
-                                      "detach the inputs (parameter gradients are available)")
         home = rain_lr.device if isinstance(rain_lr, torch.Tensor) else None
         if isinstance(rain_lr, torch.Tensor) and not rain_lr.is_cuda:
             # CPU-resident caller (the reference's test/test_model.py builds model and inputs on the
@@ -306,7 +302,9 @@ class Generator(nn.Module):
         module_dev = next(self.parameters()).device
         self._geometry(rain_lr.shape[-2], rain_lr.shape[-1], input_grid_size, module_dev)
         own = _param_list(self)
-        needs_grad = torch.is_grad_enabled() and any(p.requires_grad for p in own)
+        # (inputs with requires_grad get their gradients too, as the reference's autograd returns them)
+        needs_grad = torch.is_grad_enabled() and (any(p.requires_grad for p in own)
+                                                  or any(t.requires_grad for t in (rain_lr, dem, lu)))
         params = [p if p.device == dev else p.to(dev) for p in own]   # .to() is differentiable
         if needs_grad:
             out = rollout_with_grad(self, rain_lr, dem, lu, input_grid_size, params)

@@ -201,9 +201,10 @@ def test_reference_test_model_calls_as_written():
     g_cpu = {k: p.grad.clone() for k, p in model.named_parameters()}
     assert all(g.device.type == "cpu" and torch.isfinite(g).all() for g in g_cpu.values())
     assert float(g_cpu["cell2.conv.weight"].abs().max()) > 0
-    # inputs that ask for a gradient are refused, not silently given None
-    with pytest.raises(NotImplementedError, match="rain_lr"):
-        model(torch.rand(1, 2, 1, 8, 8, requires_grad=True), torch.rand(1, 1, 16, 16), torch.rand(1, 5, 16, 16))
+    # inputs that ask for a gradient get one, on their own device (the staging copies are differentiable)
+    rain = torch.rand(1, 2, 1, 8, 8, requires_grad=True)
+    model(rain, torch.rand(1, 1, 16, 16), torch.rand(1, 5, 16, 16)).sum().backward()
+    assert rain.grad is not None and rain.grad.device.type == "cpu" and float(rain.grad.abs().max()) > 0
 
 
 def test_errors(gpu):

@@ -19,7 +19,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(L, name), f"{name} declared in include/plconvlstm.h but not exported"
     assert declared == set(_lib.EXPORTS)
-    assert L.plc_version() == 101
+    assert L.plc_version() == 102
 
 
 def test_size_queries_without_gpu():
