@@ -408,8 +408,7 @@ def main():
             res["fwd_hbm_frac"] = FWD_BYTES_PER_PX * px * world * B * T / (dt_fwd / n_fwd) / (world * PEAK_HBM)
         # the train step against the HBM roof by MEASURED traffic: bytes of every dispatch of one step from the
         # committed PMC passes (profiles/step_traffic.py) over this run's step time
-        sj = first_existing("r3_train_c3_step_traffic.json") if B == 32 else \
-            first_existing("r3_train_c3_shard_step_traffic.json", "r2_train_c3_step_traffic.json")
+        sj = first_existing("r3_train_c3_step_traffic.json" if B == 32 else "r3_train_c3_shard_step_traffic.json")
         if args.mode == "train" and args.config == "c3" and hidden == [16, 32] and gate_dtype == "bf16" \
                 and B in (4, 32) and os.path.exists(sj):
             step_bytes = json.load(open(sj)).get("hbm_bytes_per_step")
@@ -424,11 +423,10 @@ def main():
         tk = time_cell2_kernel_fp8(Bk, H, W, device) if fp8 else time_cell2_kernel(Bk, H, W, device)
         flops = CELL2_FLOP_PER_PX * Bk * H * W
         traffic = None
-        tj = first_existing("r3_cell2_traffic.json", "r1_cell2_traffic.json")
+        tj = first_existing("r3_cell2_traffic.json")
         if os.path.exists(tj) and args.config == "c3":
-            rec = json.load(open(tj))
-            if rec.get("images_per_launch", 4) == Bk:                       # (a record of the launch size timed here)
-                traffic = rec.get("hbm_bytes_per_launch")
+            # (the record of the launch size timed here, or none)
+            traffic = json.load(open(tj))["by_images"].get(str(Bk), {}).get("hbm_bytes_per_launch")
         peak = PEAK_FP8 if fp8 else PEAK_BF16
         fp8_traffic = None
         fj = os.path.join(ROOT, "profiles", "r2_cell2_fp8_traffic.json")
@@ -456,9 +454,7 @@ def main():
             pw_traffic = None
             pj = first_existing("r3_pointwise_bwd_pair_traffic.json")
             if os.path.exists(pj) and args.config == "c3":
-                rec = json.load(open(pj))
-                if rec.get("images_per_launch") == nb:
-                    pw_traffic = rec.get("hbm_bytes_per_launch")
+                pw_traffic = json.load(open(pj))["by_images"].get(str(nb), {}).get("hbm_bytes_per_launch")
             res["roofline"] = {"bound": "hbm",
                                "kernel": f"plc_lstm_pointwise_bwd_pair_kernel (cell 2 of step t-1 + cell 1 of step t, {nb} images: "
                                          "the launch of the skewed BPTT loop" + (", one of its two half-batch chains)" if nb != B else ")"),

@@ -1,5 +1,5 @@
 """HBM bytes of ONE whole train step from the FETCH_SIZE / WRITE_SIZE passes of profiles/pmc_train.sh:
-    python3 profiles/step_traffic.py <fetch dir> <write dir> <out.json>
+    python3 profiles/step_traffic.py <fetch dir> <write dir> <out.json> [per-GPU batch of the traced run, default 4]
 The passes trace every dispatch in order; a train step ends with the optimizer's plc_clip_adam_kernel, so the
 dispatches between two of them are one step (forward, loss, backward, clip, Adam; the library's kernels and
 the few torch kernels between them).  The LAST complete step of the trace is taken.  Bytes = 2 x FETCH_SIZE +
@@ -43,7 +43,8 @@ for (_, name, f), (_, _, w) in zip(fetch, write):
     e = by_kernel.setdefault(key, {"launches": 0, "bytes": 0.0})
     e["launches"] += 1
     e["bytes"] += b
-out = {"what": "HBM bytes of one c3 train step (B=4, T=10, 256x256), PMC: 2 x FETCH_SIZE + WRITE_SIZE over every dispatch of the step",
+batch = int(sys.argv[4]) if len(sys.argv) > 4 else 4
+out = {"what": f"HBM bytes of one c3 train step (B={batch}, T=10, 256x256), PMC: 2 x FETCH_SIZE + WRITE_SIZE over every dispatch of the step",
        "dispatches": len(fetch), "hbm_bytes_per_step": total,
        "by_kernel": {k: {"launches": v["launches"], "MB": round(v["bytes"] / 1e6, 1)}
                      for k, v in sorted(by_kernel.items(), key=lambda kv: -kv[1]["bytes"])}}
