@@ -1316,12 +1316,14 @@ extern "C" int plc_generator_rollout_fwd(const plc_rollout_desc* d, void* stream
         PLC_HIP(hipStreamWaitEvent(st, side_aux->sev[1], 0));           // the gate maps are ready
         forks.joined(side_aux->side);
     }
-    if (C2 == 32 && !plc_no_post_fusion()) {
+    // (the fused kernel addresses a frame's four channel planes with 32-bit lane offsets)
+    if (C2 == 32 && !plc_no_post_fusion() && ohw * 64 < (1ll << 32)) {
         // both output convs in one kernel (plc_post_kernel.h): the 32-channel intermediate stays in LDS; a training
-        // forward also stores it for the backward pass.  Bit-identical to the two launches below.
+        // forward also stores it for the backward pass.  That intermediate is bit-identical to the first of the two
+        // launches below; the output agrees with them to fp32 rounding (the second conv sums in another order).
         PostArgs a;
         memset(&a, 0, sizeof(a));
-        a.H = oH; a.W = oW; a.n_in = B;
+        a.H = oH; a.W = oW; a.n_in = B; a.T = T;
         a.tiles_x = cdiv(oW, POST_TW);
         a.tiles_y = cdiv(oH, POST_TH);
         const long long tiles = (long long)NI * a.tiles_x * a.tiles_y;
@@ -1339,10 +1341,9 @@ extern "C" int plc_generator_rollout_fwd(const plc_rollout_desc* d, void* stream
         auto kern = save ? plc_post_fused_kernel<true> : plc_post_fused_kernel<false>;
         static bool lds_raised[2][64] = {{false}};
         if ((rc = ensure_lds_limit((const void*)kern, POST_LDS_BYTES, lds_raised[save ? 1 : 0]))) return rc;
-        // one workgroup per CU: two groups of four waves, each with its own tile buffers, taking turns
+        // one workgroup of eight waves per CU, each a contiguous run of the time-innermost tile list
         const int resident = cu_count();
-        const int want = (a.n_tiles + 1) / 2;                       // (at least two tiles per workgroup)
-        const int grid = want < resident ? (want < 1 ? 1 : want) : resident;
+        const int grid = a.n_tiles < resident ? (a.n_tiles < 1 ? 1 : a.n_tiles) : resident;
         hipLaunchKernelGGL(kern, dim3(grid), dim3(512), POST_LDS_BYTES, st, a);
         PLC_HIP(hipGetLastError());
         return PLC_OK;
