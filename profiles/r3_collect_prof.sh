@@ -35,3 +35,6 @@ echo collected
 PLC_NO_BWD_SPLIT=1 PLC_NO_FWD_SPLIT=1 PLC_NO_SIDE_STREAM=1 bash profiles/prof_run.sh r3_train_c3_shard_single_stream --shard --steps 10 --warmup 3
 PLC_NO_BWD_SPLIT=1 PLC_NO_FWD_SPLIT=1 PLC_NO_SIDE_STREAM=1 bash profiles/prof_run.sh r3_fwd_c3_shard_single_stream --shard --mode fwd --steps 20 --warmup 3
 echo single-stream stats done
+# what travels back from the GPU box is limited to 64 MiB: drop the raw traces, keep the summaries
+rm -rf gpurun_out/prof_r3_* gpurun_out/pmc_train_* gpurun_out/pmc_fwd_*
+echo cleaned
