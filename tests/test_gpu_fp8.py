@@ -115,6 +115,33 @@ def test_fp8_rollout_vs_emulation_and_fp32(gpu, shape):
     assert relmax(out16, ref) <= 2e-2
 
 
+def test_fp8_rollout_at_the_configuration_named_for_it(gpu):
+    """BASELINE configs[4] as written: one 512 x 512 element, T = 10 (forward only: ten steps of e4m3 gate operands
+    compound through the recurrence, which the short cases above do not show).  Same two bounds."""
+    from pl_convlstm_gan_amd import Generator
+    B, T, H, W = 1, 10, 512, 512
+    torch.manual_seed(71)
+    m = Generator(hidden_dims=[16, 32], lu_channels=5, scale_factor=1).to(gpu)
+    m.gate_dtype = "fp8"
+    g = torch.Generator().manual_seed(72)
+    rain = 10 * torch.rand(B, T, 1, H, W, generator=g) * (torch.rand(B, T, 1, H, W, generator=g) > 0.7)
+    dem = torch.rand(B, 1, H, W, generator=g)
+    lu = torch.nn.functional.one_hot(torch.randint(0, 5, (B, H, W), generator=g), 5).permute(0, 3, 1, 2).float().contiguous()
+    with torch.no_grad():
+        out = m(rain.to(gpu), dem.to(gpu), lu.to(gpu)).cpu()
+        params = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+        ref = O.generator_forward(params, rain, dem, lu, scale_factor=1)
+        emu = O.generator_forward(params, rain, dem, lu, scale_factor=1, emulate="fp8")
+    scale = float(ref.abs().max())
+    e_emu = float((out - emu).abs().max()) / scale
+    e_ref = relmax(out, ref)
+    # per time step: the error does not grow without bound over the rollout
+    per_t = [float((out[:, t] - ref[:, t]).abs().max()) / scale for t in range(T)]
+    print(f"fp8 512x512 T=10: vs fp8 emulation {e_emu:.3e}, vs fp32 oracle {e_ref:.3e}, per step {[round(v, 4) for v in per_t]}")
+    assert e_emu <= 4e-3
+    assert e_ref <= 2e-2
+
+
 def test_fp8_needs_the_instantiated_widths(gpu):
     from pl_convlstm_gan_amd import Generator
     m = Generator(hidden_dims=[32, 64], lu_channels=5, scale_factor=1).to(gpu)
