@@ -234,7 +234,8 @@ def test_fused_output_convs_against_the_separate_launches(gpu, tmp_path):
     launches.  The first conv's result -- which the backward pass reads -- is bit-identical, so for a loss that is
     linear in the output every parameter gradient is bit-identical too; the output itself, whose one-channel conv
     sums in another order on another matrix instruction, agrees to fp32 rounding.  Ragged sizes, tiles that
-    straddle the image border, scale 1 and through an upsample block."""
+    straddle the image border, scale 1 and through an upsample block; several tiles per workgroup with runs that
+    cross from one (batch element, tile position) chain into the next, one-frame chains, a grid smaller than a tile."""
     import os
     import subprocess
     import sys
@@ -245,7 +246,8 @@ def test_fused_output_convs_against_the_separate_launches(gpu, tmp_path):
         "from pl_convlstm_gan_amd import Generator\n"
         "gpu = torch.device('cuda:0')\n"
         "res = {}\n"
-        "for i, (B, T, H, W, seed, s) in enumerate([(2, 3, 37, 45, 8, 1), (1, 2, 64, 61, 5, 1), (2, 2, 23, 17, 9, 2), (3, 2, 128, 128, 4, 1)]):\n"
+        "for i, (B, T, H, W, seed, s) in enumerate([(2, 3, 37, 45, 8, 1), (1, 2, 64, 61, 5, 1), (2, 2, 23, 17, 9, 2), (3, 2, 128, 128, 4, 1), "
+        "(2, 5, 200, 190, 3, 1), (1, 1, 5, 7, 6, 1), (4, 1, 60, 33, 7, 1)]):\n"
         "    torch.manual_seed(seed)\n"
         "    m = Generator(hidden_dims=[16, 32], lu_channels=5, scale_factor=s).to(gpu)\n"
         "    g = torch.Generator().manual_seed(seed + 1)\n"
