@@ -392,7 +392,8 @@ def main():
             "dtype": gate_dtype if gate_dtype == "fp8" else "bf16", "data": "synthetic",
             "config": {"workload": f"{args.config}: {what}, B={B}/GPU, T={T}, {H}x{W} -> {H * s}x{W * s}, 1 channel, "
                                    f"hidden [{args.hidden}], L=5, scale_factor={s}, {N_STATIONS} stations, gate convs {gate_dtype}"
-                                   + (" (e4m3 operands, fp32 accumulate; every other conv and the backward pass bf16)" if gate_dtype == "fp8" else ""),
+                                   + (" (e4m3 operands, fp32 accumulate; every other conv and the backward pass bf16; the path BASELINE "
+                                      "configs[4] names -- with --gate-dtype bf16 the same configuration measures within 2 %)" if gate_dtype == "fp8" else ""),
                        "global_batch": world * B, "T": T, "mode": args.mode + (" (HIP-graph replay)" if args.graph else ""),
                        "parallelism": f"dp{world} (batch sharded; one flat-gradient all-reduce per step)"},
             "fwd_frames_per_s": world * B * T * n_fwd / dt_fwd,
