@@ -221,26 +221,24 @@ __global__ __launch_bounds__(512, 1) void plc_post_fused_kernel(const PostArgs a
         y0 = it.ty * POST_TH;
     };
     // The 18 x 34 input neighbourhood of a tile (rows y0-2 .. y0+15, columns x0-2 .. x0+31): thread t takes units
-    // t + 512 q, q < 5.  All of a thread's loads are in flight together; a load is a scalar base plus a 32-bit lane
-    // offset (the launcher checks that four channel planes fit 32 bits).  A unit outside the image (or past the
-    // tile's last unit) loads the tile's own first pixel instead, which always exists, and is zeroed when it is
-    // consumed.  Nothing about a unit is kept in registers between tiles: every register that lives across the first
-    // conv's MFMA loop is one the allocator spills, and a spill reload between two loads makes the second wait for
-    // the first (scratch accesses count on vmcnt), so a lane's unit coordinates are recomputed per tile from an
-    // operand the compiler cannot see through (`opaque`), a dozen integer instructions per unit.
+    // t + 512 q, q < 5.  A load is a scalar base plus a 32-bit lane offset (the launcher checks that four channel
+    // planes fit 32 bits); the offset of a unit from the neighbourhood's first unit is the one thing kept per unit
+    // (five registers).  A unit outside the image, or past the tile's last unit, loads the tile's own first pixel
+    // instead, which always exists, and is zeroed when it is consumed.  Only tiles that touch the image border test
+    // bounds per lane, from coordinates recomputed on the spot behind an operand the compiler cannot see through
+    // (`opaque_zero`): hoisted, they would be a dozen more registers living across the first conv's MFMA loop, where
+    // the allocator is at its limit, and a spill reload between two loads makes the second wait for the first
+    // (scratch accesses count on vmcnt).
     constexpr int NIT = (POST_IN_UNITS + 511) / 512;      // 5
     auto tile_inner = [&](int x0, int y0) { return y0 >= 2 && y0 + POST_TH + 2 <= H && x0 >= 2 && x0 + POST_TW + 2 <= W; };
-    auto unit_ok = [&](int u, int x0, int y0, bool inner) {
+    // does unit u of the neighbourhood of the tile at (x0, y0) exist?
+    auto unit_ok = [&](int u, int x0, int y0) {
         const int cb = u / (POST_IH * POST_IW), r = u - cb * (POST_IH * POST_IW);
         const int ly = r / POST_IW, lx = r - ly * POST_IW;
         const int gy = y0 - 2 + ly, gx = x0 - 2 + lx;
-        bool ok = u < POST_IN_UNITS;
-        if (!inner) ok = ok & (gy >= 0) & (gy < H) & (gx >= 0) & (gx < W);
-        return ok;
+        return (u < POST_IN_UNITS) & (gy >= 0) & (gy < H) & (gx >= 0) & (gx < W);
     };
-    // (the one thing kept per unit: its byte offset from the neighbourhood's first unit, the tile's own first pixel
-    // for the units past the last; five registers)
-    const unsigned safe = (unsigned)(2 * W + 2) * 16u;
+    const unsigned safe = (unsigned)(2 * W + 2) * 16u;        // the tile's own first pixel
     unsigned off[NIT];
 #pragma unroll
     for (int q = 0; q < NIT; ++q) {
@@ -269,14 +267,14 @@ __global__ __launch_bounds__(512, 1) void plc_post_fused_kernel(const PostArgs a
     // compiler keep off[] in scratch memory and load it, on the vmcnt counter, before every request)
     auto request_unit = [&](const Stage& st, int q, unsigned o, uint4& v) {
         if (!st.inner) {
-            const unsigned keep = unit_ok(tid + q * 512 + opaque_zero(), st.x0, st.y0, false) ? 0xffffffffu : 0u;
+            const unsigned keep = unit_ok(tid + q * 512 + opaque_zero(), st.x0, st.y0) ? 0xffffffffu : 0u;
             o = (o & keep) | (safe & ~keep);
         }
         v = plc_gload16(st.org + o);
     };
     // zero unit q if it does not exist (border tiles; the tail past the tile's last unit is never stored)
     auto mask_unit = [&](const Stage& st, int q, uint4& v) {
-        if (!st.inner && !unit_ok(tid + q * 512 + opaque_zero(), st.x0, st.y0, false)) v = make_uint4(0u, 0u, 0u, 0u);
+        if (!st.inner && !unit_ok(tid + q * 512 + opaque_zero(), st.x0, st.y0)) v = make_uint4(0u, 0u, 0u, 0u);
     };
     // A tile that begins a chain fetches this thread's gate units (the only wait for memory in the loop, once per T
     // tiles).  tgate[u] is written and read by the same thread only.
@@ -292,9 +290,8 @@ __global__ __launch_bounds__(512, 1) void plc_post_fused_kernel(const PostArgs a
             if ((q + 1) * 512 <= POST_IN_UNITS || u < POST_IN_UNITS) tgate[u] = g[q];
         }
     };
-    // unit q of a tile's gated input from its feature unit f: the product, rounded to bf16 once
-    // (g: the thread's gate unit q, read from tgate beforehand: an LDS read inside the MFMA loop would make the loop
-    // wait for every fragment read in flight, LDS reads return in order)
+    // unit q of a tile's gated input from its feature unit f and the thread's gate unit g: the product, rounded to
+    // bf16 once
     auto product_unit = [&](const Stage& st, int q, uint4 f, uint4 g, uint4* dst) {
         mask_unit(st, q, f);
         const int u = tid + q * 512;
@@ -307,8 +304,9 @@ __global__ __launch_bounds__(512, 1) void plc_post_fused_kernel(const PostArgs a
     };
     uint4 pf[NIT];      // this thread's feature units of the tile after the one being convolved
     // First conv + ReLU on rows y0-1 .. y0+14, columns x0-1 .. x0+30 -> tp0 (zero outside the image).  Behind its
-    // MFMAs: the product of the NEXT tile into the other input buffer (from the units requested a round ago), then
-    // the request of the tile after that into the same registers.
+    // MFMAs: the request of tile it_r's feature units into pf, one unit every other fragment.  (The product does
+    // not go there: its temporaries get the fragment ring's registers from the allocator and every slice then waits
+    // for the MFMA that still reads them; an LDS read in the loop would wait for every fragment read in flight.)
     auto conv_first = [&](const Item& it, const uint4* tin, const Item& it_r) {
         int n, x0, y0;
         coords(it, n, x0, y0);
