@@ -12,6 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # (PLC_LIB_PATH: load another build of the library instead, e.g. an older one for a same-box comparison)
 LIB_PATH = os.environ.get("PLC_LIB_PATH") or os.path.join(_HERE, "libplconvlstm.so")
 
+ABI_VERSION = 102      # PLC_VERSION of the include/plconvlstm.h these bindings mirror
 EXPORTS = (
     "plc_version", "plc_last_error",
     "plc_nchw_f32_to_cb8_bf16", "plc_cb8_bf16_to_nchw_f32", "plc_nchw_f32_to_cb8_f32", "plc_cb8_f32_to_nchw_f32",
@@ -105,6 +106,11 @@ def lib():
     L = C.CDLL(LIB_PATH)
     i, sz, p = C.c_int, C.c_size_t, C.c_void_p
     L.plc_version.restype = i
+    if L.plc_version() != ABI_VERSION:
+        # the structures below mirror ONE version of include/plconvlstm.h: a library built from another one would
+        # read their fields at the wrong offsets
+        raise RuntimeError(f"{LIB_PATH} is version {L.plc_version()} of the C ABI, this binding is version {ABI_VERSION}: "
+                           "rebuild it (`python -c 'import __graft_entry__ as g; g.build()'`)")
     L.plc_last_error.restype = C.c_char_p
     for name in ("plc_nchw_f32_to_cb8_bf16", "plc_cb8_bf16_to_nchw_f32", "plc_nchw_f32_to_cb8_f32",
                  "plc_cb8_f32_to_nchw_f32"):

@@ -19,7 +19,8 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(L, name), f"{name} declared in include/plconvlstm.h but not exported"
     assert declared == set(_lib.EXPORTS)
-    assert L.plc_version() == 102
+    # the header, the built library and the ctypes mirror are one version
+    assert L.plc_version() == _lib.ABI_VERSION == int(re.search(r"#define PLC_VERSION (\d+)", hdr).group(1))
 
 
 def test_size_queries_without_gpu():
