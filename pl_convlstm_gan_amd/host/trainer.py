@@ -102,6 +102,12 @@ class Trainer:
         self.best_rmse = float("inf")
         self.best_epoch = -1
         self.optimize_lazy_blocks = False
+        # PLC_GRAPH_STEP=1: replay the training step as a HIP graph (training.GraphedTrainStep) from the second batch
+        # on, one captured graph per batch shape.  It pays where a step is launch-bound (the 15 x 12 basin grid of
+        # default.yaml: about a fifth off the step) and costs a few per cent at 256 x 256; single process only.
+        self.graph_steps = os.environ.get("PLC_GRAPH_STEP", "") not in ("", "0")
+        self._graphed = {}
+        self._eager_steps = 0
         self.early_stopping = None
         tr = self.config.training
         if getattr(tr, "use_early_stopping", False):
@@ -229,10 +235,20 @@ class Trainer:
             # (under data parallelism the loader already yields this rank's slice of the batch, and drops batches
             # with fewer samples than ranks on every rank alike: ShardedBatchSampler)
             lr, dem, lu, s_coords, s_values = self._to_device(batch)
-            loss, parts, fake_hr, skipped = train_step(
-                self.model, self.loss_module, self.optimizer, lr, dem, lu, s_coords, s_values,
-                max_norm=self.config.training.grad_clip_norm, forward_kwargs=self._forward_kwargs(),
-                nan_check="device")     # the skip is decided by the optimizer kernel; `skipped` is read below, after the step is queued
+            step = self._graphed_step((lr, dem, lu, s_coords, s_values))
+            if step is not None:
+                loss, parts, fake_hr, skipped = step(lr, dem, lu, s_coords, s_values)
+            else:
+                loss, parts, fake_hr, skipped = train_step(
+                    self.model, self.loss_module, self.optimizer, lr, dem, lu, s_coords, s_values,
+                    max_norm=self.config.training.grad_clip_norm, forward_kwargs=self._forward_kwargs(),
+                    nan_check="device")     # the skip is decided by the optimizer kernel; `skipped` is read below, after the step is queued
+                self._eager_steps += 1
+                if self.graph_steps:
+                    # nothing of this step's autograd graph may outlive it: a capture must not find the
+                    # parameters' gradient-accumulation nodes bound to this step's stream
+                    loss, fake_hr = loss.detach(), fake_hr.detach()
+                    parts = {k: (v.detach() if torch.is_tensor(v) else v) for k, v in parts.items()}
             if self.optimize_lazy_blocks and self.model.upsample_blocks is not None and len(self.optimizer.param_groups) == 1 \
                     and len(self.model.upsample_blocks) > 0:
                 self.optimizer.add_param_group({"params": list(self.model.upsample_blocks.parameters())})
@@ -253,6 +269,20 @@ class Trainer:
                       f"Temporal: {sums['temporal'][-1]:.4f} | Batch RMSE: {rmse.item():.4f}")
         avg = {k: (float(np.mean(v)) if v else 0.0) for k, v in sums.items()}
         return rmses, last[0], last[1], last[2], last[3], avg
+
+    def _graphed_step(self, batch):
+        """The captured step for this batch's shape, or None when the step runs eagerly: the switch is off, more
+        than one process trains, or this is the first step (which creates the lazy upsample blocks and, with
+        ``optimize_lazy_blocks``, changes what the optimizer owns)."""
+        if not self.graph_steps or _rank_world()[1] > 1 or self._eager_steps == 0 or not batch[0].is_cuda:
+            return None
+        key = tuple(tuple(t.shape) for t in batch)
+        if key not in self._graphed:
+            from ..training import GraphedTrainStep
+            self._graphed[key] = GraphedTrainStep(self.model, self.loss_module, self.optimizer, batch,
+                                                  max_norm=self.config.training.grad_clip_norm,
+                                                  forward_kwargs=self._forward_kwargs())
+        return self._graphed[key]
 
     def _checkpoint(self, epoch, rmse):
         path = os.path.join(self.output_dir, "best_model.pth")

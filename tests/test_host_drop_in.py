@@ -112,3 +112,42 @@ def test_trainer_end_to_end_on_synthetic_basin(gpu, tmp_path, monkeypatch):
     t2 = Trainer("synthetic")
     t2.setup_model(t2.setup_data())
     assert t2.resume(os.path.join(t.output_dir, "best_model.pth")) == ck["epoch"] + 1
+
+
+@pytest.mark.gpu
+def test_trainer_with_graph_replayed_steps_matches_the_eager_trainer(gpu, tmp_path, monkeypatch):
+    """PLC_GRAPH_STEP=1: the Trainer replays the step as a HIP graph (one per batch shape: the last batch of an
+    epoch is shorter) between its own host work -- station RMSE through indexing kernels, validation forwards,
+    checkpoints with .cpu() copies, a scheduler.  Same seeded batch order in both runs: the epoch history and the
+    final parameters are bit-equal to the eager Trainer's."""
+    from pl_convlstm_gan_amd.host import config as C
+    from pl_convlstm_gan_amd.host.datasets import write_synthetic_dataset
+    paths = write_synthetic_dataset(str(tmp_path / "basin"), start_year=2012, end_year=2013, lr_hw=(15, 12), scale=2,
+                                    n_stations=10)
+    cfg = C.Config()
+    for k, v in paths.items():
+        setattr(cfg.data, k, v)
+    cfg.model.scale_factor = 2
+    cfg.training.batch_size = 16
+    cfg.training.epochs = 2
+    cfg.training.train_years, cfg.training.val_years, cfg.training.test_years = [2012, 2012], [2013, 2013], [2013, 2013]
+    cfg.output.log_interval = 100
+    cfg_dir = tmp_path / "configs"
+    monkeypatch.setattr(C, "CONFIG_DIR", str(cfg_dir))
+    monkeypatch.setenv("PLC_SHUFFLE_SEED", "5")           # the same batch order in both runs
+    from src.training.trainer import Trainer
+    runs = {}
+    for tag, flag in (("eager", "0"), ("graph", "1")):
+        cfg.output.output_dir = str(tmp_path / f"out_{tag}")
+        cfg.to_yaml(str(cfg_dir / "synthetic.yaml"))
+        monkeypatch.setenv("PLC_GRAPH_STEP", flag)
+        torch.manual_seed(11)                              # the same initial weights (and lazy block) in both runs
+        t = Trainer("synthetic")
+        assert t.graph_steps == (flag == "1")
+        t.train()
+        if flag == "1":
+            assert len(t._graphed) == 2                    # full batches and the shorter last one
+        runs[tag] = (t.history, {k: v.detach().cpu() for k, v in t.model.state_dict().items()})
+    assert runs["eager"][0] == runs["graph"][0]
+    for k, v in runs["eager"][1].items():
+        assert torch.equal(v, runs["graph"][1][k]), k
