@@ -185,20 +185,34 @@ class Trainer:
         return tuple(t.to(self.device) for t in batch)
 
     # ------------------------------------------------------------------ evaluation
-    def compute_station_rmse(self, fake_hr, s_coords, s_values, scale_factor=1.0):
-        """(rmse, pred_at_stations, true_vals, valid_station_mask, mask): trainer.py:225-272."""
+    def compute_station_rmse(self, fake_hr, s_coords, s_values, scale_factor=1.0, coords_host=None):
+        """(rmse, pred_at_stations, true_vals, valid_station_mask, mask): trainer.py:225-272.
+
+        Same quantities as the reference, arranged so that the host does not wait for the GPU: the gauge pixels are
+        a few dozen integers, so their index arithmetic runs on the host (``coords_host``: the batch's s_coords
+        before it went to the device, when the caller still has it; otherwise one small copy back) and the
+        gathers take index tensors instead of boolean masks (a mask makes PyTorch count its set bits on the host
+        first).  The mean over the observed values is a masked sum over a count, decided on the device."""
         B, T, _, H, W = fake_hr.shape
         coords = s_coords[0] if s_coords.dim() == 3 else s_coords
-        hr = ((coords.float() + 0.5) * scale_factor - 0.5).long()
+        if coords_host is None:
+            coords_host = coords
+        ch = coords_host[0] if coords_host.dim() == 3 else coords_host
+        hr = ((ch.detach().cpu().float() + 0.5) * scale_factor - 0.5).long()         # gauge pixel, as combined_loss.py:79-141
         rows, cols = hr[:, 0], hr[:, 1]
-        inside = (rows >= 0) & (rows < H) & (cols >= 0) & (cols < W)
-        zero = torch.tensor(0.0, device=fake_hr.device)
-        if int(inside.sum()) == 0:
+        inside_h = (rows >= 0) & (rows < H) & (cols >= 0) & (cols < W)
+        inside = inside_h.to(fake_hr.device)
+        zero = fake_hr.new_zeros(())
+        if not bool(inside_h.any()):
             return zero, None, None, inside, None
-        at = fake_hr[:, :, 0][:, :, rows[inside], cols[inside]]
-        truth = s_values[:, :, inside]
+        keep = torch.nonzero(inside_h).flatten()
+        idx = torch.stack([rows[keep], cols[keep], keep]).to(fake_hr.device)          # one small upload
+        at = fake_hr[:, :, 0][:, :, idx[0], idx[1]]
+        truth = s_values.index_select(2, idx[2])
         seen = ~torch.isnan(truth)
-        rmse = torch.sqrt(((at[seen] - truth[seen]) ** 2).mean()) if int(seen.sum()) > 0 else zero
+        diff = torch.where(seen, at - truth, zero)
+        count = seen.sum()
+        rmse = torch.where(count > 0, torch.sqrt((diff * diff).sum() / count.clamp(min=1)), zero)
         return rmse, at, truth, inside, seen
 
     def validate(self):
@@ -260,7 +274,8 @@ class Trainer:
                 sums[k].append(float(parts[k].detach()))
             with torch.no_grad():
                 sf = fake_hr.shape[-2] / lr.shape[-2]
-                rmse, at, truth, inside, _ = self.compute_station_rmse(fake_hr.detach(), s_coords, s_values, sf)
+                rmse, at, truth, inside, _ = self.compute_station_rmse(fake_hr.detach(), s_coords, s_values, sf,
+                                                                       coords_host=batch[3])
                 rmses.append(rmse.item())
                 last = (at, truth, s_coords, inside)
             if i % self.config.output.log_interval == 0 and _rank_world()[0] == 0:

@@ -79,6 +79,31 @@ def test_negative_repair_rule():
     assert np.allclose(out, [2, 2, 3, 4, 4, 3.5, 3])
 
 
+def test_station_rmse_against_the_restatement():
+    """Trainer.compute_station_rmse (trainer.py:225-272) in its no-host-wait form equals the plain restatement:
+    gauges outside the grid dropped, unobserved (NaN) values skipped, 0 when nothing is observed."""
+    from oracle import cpu_oracle as O
+    from pl_convlstm_gan_amd.host.trainer import Trainer
+    g = torch.Generator().manual_seed(4)
+    pred = torch.rand(3, 4, 1, 24, 20, generator=g)
+    coords = torch.tensor([[0, 0], [11, 9], [5, 3], [12, 2], [3, 10], [7, 7]])          # LR cells; x2: (12, .) and (., 10) fall outside
+    coords = coords.unsqueeze(0).repeat(3, 1, 1)
+    values = 20 * torch.rand(3, 4, 6, generator=g)
+    values[0, 1, 2] = float("nan")
+    values[2, :, 5] = float("nan")
+    rmse, at, truth, inside, seen = Trainer.compute_station_rmse(None, pred, coords, values, 2.0)
+    assert inside.tolist() == [True, True, True, False, False, True]
+    assert at.shape == truth.shape == seen.shape == (3, 4, 4) and int(seen.sum()) == 3 * 4 * 4 - 1 - 4
+    assert torch.equal(at[:, :, 1], pred[:, :, 0, 22, 18]) and torch.equal(truth[:, :, 3].isnan(), values[:, :, 5].isnan())
+    assert abs(float(rmse) - O.station_rmse(pred, coords, values, 2.0)) <= 1e-6 * float(rmse)
+    # the batch's host copy of the coordinates gives the same thing
+    assert float(Trainer.compute_station_rmse(None, pred, coords, values, 2.0, coords_host=coords.clone())[0]) == float(rmse)
+    # nothing observed / nothing inside
+    assert float(Trainer.compute_station_rmse(None, pred, coords, torch.full_like(values, float("nan")), 2.0)[0]) == 0.0
+    out = Trainer.compute_station_rmse(None, pred, coords + 100, values, 2.0)
+    assert float(out[0]) == 0.0 and out[1] is None and not bool(out[3].any())
+
+
 @pytest.mark.gpu
 def test_trainer_end_to_end_on_synthetic_basin(gpu, tmp_path, monkeypatch):
     from pl_convlstm_gan_amd.host import config as C
