@@ -48,6 +48,9 @@ def shard_bounds(n, rank, world):
     return rank * n // world, (rank + 1) * n // world
 
 
+_STATION_INDEX_CACHE = {}      # compute_station_rmse: (gauge coordinates, grid, scale, device) -> device index tensors
+
+
 class ShardedBatchSampler:
     """Data parallelism at the loader: wraps a batch sampler and yields, on every rank, only this rank's slice
     of each batch's indices (shard_bounds), so a rank loads and copies to its GPU just the samples it trains on.
@@ -198,15 +201,25 @@ class Trainer:
         if coords_host is None:
             coords_host = coords
         ch = coords_host[0] if coords_host.dim() == 3 else coords_host
-        hr = ((ch.detach().cpu().float() + 0.5) * scale_factor - 0.5).long()         # gauge pixel, as combined_loss.py:79-141
-        rows, cols = hr[:, 0], hr[:, 1]
-        inside_h = (rows >= 0) & (rows < H) & (cols >= 0) & (cols < W)
-        inside = inside_h.to(fake_hr.device)
+        ch = ch.detach().cpu()
+        # The gauges are the same in every batch: their device-side index tensors are kept, keyed by the coordinates
+        # themselves, so that a batch uploads nothing here (an upload from pageable memory makes the host wait for
+        # everything queued on the stream, i.e. for the training step just launched).
+        key = (ch.numpy().tobytes(), tuple(ch.shape), H, W, float(scale_factor), str(fake_hr.device))
+        cache = _STATION_INDEX_CACHE
+        if key not in cache:
+            if len(cache) >= 16:
+                cache.clear()
+            hr = ((ch.float() + 0.5) * scale_factor - 0.5).long()                    # gauge pixel, as combined_loss.py:79-141
+            rows, cols = hr[:, 0], hr[:, 1]
+            inside_h = (rows >= 0) & (rows < H) & (cols >= 0) & (cols < W)
+            keep = torch.nonzero(inside_h).flatten()
+            cache[key] = (inside_h.to(fake_hr.device), bool(inside_h.any()),
+                          torch.stack([rows[keep], cols[keep], keep]).to(fake_hr.device))
+        inside, any_inside, idx = cache[key]
         zero = fake_hr.new_zeros(())
-        if not bool(inside_h.any()):
+        if not any_inside:
             return zero, None, None, inside, None
-        keep = torch.nonzero(inside_h).flatten()
-        idx = torch.stack([rows[keep], cols[keep], keep]).to(fake_hr.device)          # one small upload
         at = fake_hr[:, :, 0][:, :, idx[0], idx[1]]
         truth = s_values.index_select(2, idx[2])
         seen = ~torch.isnan(truth)
@@ -245,7 +258,13 @@ class Trainer:
         rmses = []
         sums = {k: [] for k in ("total", "point", "conserve", "smooth", "temporal")}
         last = (None, None, None, None)
-        for i, batch in enumerate(self.train_loader):
+        # The step is queued without waiting for its loss, so the host fetches the NEXT batch from the loader while the
+        # GPU works on this one, and reads this one's loss afterwards (same batches in the same order).
+        batches = iter(self.train_loader)
+        upcoming = next(batches, None)
+        i = -1
+        while upcoming is not None:
+            batch, i = upcoming, i + 1
             # (under data parallelism the loader already yields this rank's slice of the batch, and drops batches
             # with fewer samples than ranks on every rank alike: ShardedBatchSampler)
             lr, dem, lu, s_coords, s_values = self._to_device(batch)
@@ -266,22 +285,28 @@ class Trainer:
             if self.optimize_lazy_blocks and self.model.upsample_blocks is not None and len(self.optimizer.param_groups) == 1 \
                     and len(self.model.upsample_blocks) > 0:
                 self.optimizer.add_param_group({"params": list(self.model.upsample_blocks.parameters())})
-            if skipped:
-                print("NaN detected, skip this batch")
-                continue
-            sums["total"].append(loss.item())
-            for k in ("point", "conserve", "smooth", "temporal"):
-                sums[k].append(float(parts[k].detach()))
+            # the station RMSE of this batch is queued behind the step (nothing in it waits for the GPU) ...
             with torch.no_grad():
                 sf = fake_hr.shape[-2] / lr.shape[-2]
                 rmse, at, truth, inside, _ = self.compute_station_rmse(fake_hr.detach(), s_coords, s_values, sf,
                                                                        coords_host=batch[3])
-                rmses.append(rmse.item())
-                last = (at, truth, s_coords, inside)
+                # ... and everything the log needs comes back in ONE read, after the next batch has been fetched
+                scalars = torch.stack([loss.detach().float().reshape(())]
+                                      + [torch.as_tensor(parts[k], dtype=torch.float32, device=loss.device).detach().reshape(())
+                                         for k in ("point", "conserve", "smooth", "temporal")]
+                                      + [rmse.float().reshape(())])
+            upcoming = next(batches, None)
+            if skipped:
+                print("NaN detected, skip this batch")
+                continue
+            total, point, conserve, smooth, temporal, batch_rmse = scalars.tolist()
+            for k, v in zip(("total", "point", "conserve", "smooth", "temporal"), (total, point, conserve, smooth, temporal)):
+                sums[k].append(v)
+            rmses.append(batch_rmse)
+            last = (at, truth, s_coords, inside)
             if i % self.config.output.log_interval == 0 and _rank_world()[0] == 0:
-                print(f"Epoch {epoch} | Loss: {loss.item():.4f} | Point: {sums['point'][-1]:.4f} | "
-                      f"Conserve: {sums['conserve'][-1]:.4f} | Smooth: {sums['smooth'][-1]:.4f} | "
-                      f"Temporal: {sums['temporal'][-1]:.4f} | Batch RMSE: {rmse.item():.4f}")
+                print(f"Epoch {epoch} | Loss: {total:.4f} | Point: {point:.4f} | Conserve: {conserve:.4f} | "
+                      f"Smooth: {smooth:.4f} | Temporal: {temporal:.4f} | Batch RMSE: {batch_rmse:.4f}")
         avg = {k: (float(np.mean(v)) if v else 0.0) for k, v in sums.items()}
         return rmses, last[0], last[1], last[2], last[3], avg
 
