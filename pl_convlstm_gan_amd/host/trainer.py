@@ -246,8 +246,11 @@ class Trainer:
                 fake_hr = self.model(lr, dem, lu, **self._forward_kwargs())
                 sf = fake_hr.shape[-2] / lr.shape[-2]
                 loss, _ = self.loss_module(fake_hr, lr, s_coords, s_values, sf)
-                losses.append(loss.item())
-                rmses.append(self.compute_station_rmse(fake_hr, s_coords, s_values, sf)[0].item())
+                losses.append(loss.detach().float().reshape(()))
+                rmses.append(self.compute_station_rmse(fake_hr, s_coords, s_values, sf, coords_host=batch[3])[0].float().reshape(()))
+            # (one read for the whole pass instead of two host waits per batch)
+            losses = torch.stack(losses).tolist() if losses else []
+            rmses = torch.stack(rmses).tolist() if rmses else []
         self.model.train()
         loss_sum, rmse_sum, n = sum_over_ranks([float(np.sum(losses)), float(np.sum(rmses)), len(losses)])
         return {"loss": loss_sum / n, "rmse": rmse_sum / n} if n else {"loss": float("nan"), "rmse": float("nan")}
