@@ -257,6 +257,9 @@ def main():
                     help="train mode, one GPU: capture the step into a HIP graph and replay it (pays on launch-bound "
                          "shapes such as c0 / p2 / c1; the large configs are GPU-bound either way)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--roofline-only", action="store_true",
+                    help="skip the timed steps and only time the roofline kernels' stand-alone launches (for a profiler "
+                         "trace that holds nothing else under those kernel names); the line's throughput fields are null")
     ap.add_argument("--shape", default=None, help="B,T,H,W,scale in place of the named configuration's (measurement aid: "
                                                   "the line then describes that shape, not a BASELINE configuration)")
     args = ap.parse_args()
@@ -375,9 +378,13 @@ def main():
         return dt
 
     main_fn = step_train if args.mode == "train" else step_fwd
-    dt = timed(main_fn, args.steps, args.warmup)
-    # the forward-only leg of a train run gets the same warm-up and step count as the train leg
-    dt_fwd = timed(step_fwd, args.steps, args.warmup) if args.mode == "train" else dt
+    if args.roofline_only:
+        dt = dt_fwd = float("nan")
+        args.no_cpu_baseline = True
+    else:
+        dt = timed(main_fn, args.steps, args.warmup)
+        # the forward-only leg of a train run gets the same warm-up and step count as the train leg
+        dt_fwd = timed(step_fwd, args.steps, args.warmup) if args.mode == "train" else dt
     n_fwd = args.steps
 
     if rank == 0:
@@ -473,6 +480,9 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             params = {k: v.detach().cpu() for k, v in model.state_dict().items()}
             res["cpu_baseline"] = cpu_baseline(args.mode, B, T, H, W, s, params)
+        if args.roofline_only:
+            res = {k: v for k, v in res.items() if k in ("n_gpus", "dtype", "config", "roofline", "roofline_mfma")}
+            res["roofline_only"] = True
         print(json.dumps(res), flush=True)
     if world > 1:
         barrier()        # rank 0 is still timing the roofline kernel / printing: leave together

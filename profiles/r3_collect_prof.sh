@@ -34,6 +34,14 @@ echo collected
 # durations that do not overlap, for the kernel table
 PLC_NO_BWD_SPLIT=1 PLC_NO_FWD_SPLIT=1 PLC_NO_SIDE_STREAM=1 bash profiles/prof_run.sh r3_train_c3_shard_single_stream --shard --steps 10 --warmup 3
 PLC_NO_BWD_SPLIT=1 PLC_NO_FWD_SPLIT=1 PLC_NO_SIDE_STREAM=1 bash profiles/prof_run.sh r3_fwd_c3_shard_single_stream --shard --mode fwd --steps 20 --warmup 3
+# ... and the default (global batch 32) step the same way: here the pointwise pair launch of grid 6 291 456 (16 images) is
+# only bench.py's own roofline timing (the single-stream step launches it on the whole batch, grid 12 582 912), so that
+# row of the by-grid table is the stand-alone duration the bench line's roofline object reports
+PLC_NO_BWD_SPLIT=1 PLC_NO_FWD_SPLIT=1 PLC_NO_SIDE_STREAM=1 bash profiles/prof_run.sh r3_train_c3_single_stream --steps 10 --warmup 3
+# the roofline kernels' stand-alone launches and nothing else under their names: these averages are what the bench
+# lines' roofline objects report (launch_us)
+bash profiles/prof_run.sh r3_roofline_launches --roofline-only
+bash profiles/prof_run.sh r3_roofline_launches_shard --roofline-only --shard
 echo single-stream stats done
 # what travels back from the GPU box is limited to 64 MiB: drop the raw traces, keep the summaries
 rm -rf gpurun_out/prof_r3_* gpurun_out/pmc_train_* gpurun_out/pmc_fwd_*
